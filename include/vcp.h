@@ -1,0 +1,171 @@
+/*
+ * vcp.h -- C-ABI of libvcp.so: MI355X (gfx950) DBSCAN + centroid + ICP hot path of
+ * ZhiHuangHn/vtkCloudPoint.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Each entry point replaces one piece of the reference's C# class surface; the citation
+ * (file:line under /root/reference/vtkPointCloud/, BC = BaseClass) names what it stands in
+ * for.  The C# side binds these with [DllImport("vcp")] -- see INTEGRATION.md.
+ *
+ * Conventions
+ *  - every call is blocking and re-entrant per context (one vcp_ctx per caller thread, the
+ *    way FrmMain.cs:1358 runs one DBImproved per pool thread); the library keeps no pointer
+ *    after a call returns;
+ *  - return value: 0 = VCP_OK, < 0 = error (vcp_last_error(ctx) gives the text);
+ *  - "host" entry points take caller-owned host buffers and do H2D/D2H themselves;
+ *    "_dev" entry points take device pointers (inputs already resident in HBM) and run on
+ *    the context's stream;
+ *  - there is NO CPU fallback: without a HIP device every compute call fails with
+ *    VCP_ERR_NO_DEVICE.
+ */
+#ifndef VCP_H
+#define VCP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VCP_VERSION_MAJOR 0
+#define VCP_VERSION_MINOR 1
+
+typedef struct vcp_ctx vcp_ctx;
+
+/* distance forms: BC/DBImproved.cs:21 (live, |dx|+|dy| on motor_x/motor_y), :24 and :20
+ * (commented-out Euclidean 2-D / 3-D), BC/DB.cs:21 (dead v1.0 class, signed dx+dy). */
+enum vcp_metric { VCP_L1_2D = 0, VCP_L2_2D = 1, VCP_L2_3D = 2, VCP_SIGNED_SUM_2D = 3 };
+
+/* ICP stop rules: BC/ICP.cs:180 (|SSE - previous SSE| < e) or RMSE = sqrt(SSE/Nd) < e. */
+enum vcp_icp_stop { VCP_STOP_SSE_DELTA = 0, VCP_STOP_RMSE = 1 };
+
+enum vcp_status {
+  VCP_OK = 0,
+  VCP_ERR_ARG = -1,          /* invalid argument                                           */
+  VCP_ERR_EMPTY = -2,        /* the C# would throw on an empty collection                  */
+  VCP_ERR_DEGENERATE = -3,   /* zero-extent first block: rows/cols undefined               */
+  VCP_ERR_INDEX = -4,        /* the C# would throw IndexOutOfRange / ArgumentOutOfRange    */
+  VCP_ERR_TOO_LARGE = -5,    /* n or grid beyond 32-bit indexing                           */
+  VCP_ERR_NO_DEVICE = -6,    /* no HIP device / device id out of range                     */
+  VCP_ERR_HIP = -7,          /* HIP runtime error                                          */
+  VCP_ERR_UNSUPPORTED = -8,  /* valid request this build does not run on the GPU           */
+  VCP_ERR_NOMEM = -9
+};
+
+/* -- context ------------------------------------------------------------------------------ */
+/* device_id: HIP ordinal (one context drives one GPU; multi-GPU = one process per GPU). */
+int vcp_create(int device_id, vcp_ctx** out);
+void vcp_destroy(vcp_ctx* ctx);
+const char* vcp_last_error(const vcp_ctx* ctx); /* ctx may be NULL: last create error      */
+int vcp_version(void);                           /* major*1000 + minor                      */
+/* Run on a caller-provided hipStream_t (NULL = the context's own stream). */
+int vcp_set_stream(vcp_ctx* ctx, void* hip_stream);
+/* Pinned-free device allocation helpers for hosts without a HIP binding of their own. */
+int vcp_dev_alloc(vcp_ctx* ctx, uint64_t bytes, void** dptr);
+int vcp_dev_free(vcp_ctx* ctx, void* dptr);
+int vcp_h2d(vcp_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
+int vcp_d2h(vcp_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
+
+/* -- per-phase device timing (hipEvents on the launch stream) ----------------------------- */
+/* When enabled, every compute call records hipEvents around each kernel phase on the stream
+ * it launches on.  vcp_timing_get returns the phases of the LAST call. */
+int vcp_timing_enable(vcp_ctx* ctx, int on);
+int vcp_timing_count(vcp_ctx* ctx);
+int vcp_timing_get(vcp_ctx* ctx, int i, const char** name, float* ms);
+
+/* -- DBSCAN -------------------------------------------------------------------------------
+ * Replaces DBImproved.dbscan(List<Point3D> lst, double e, int minPts), BC/DBImproved.cs:91-114
+ * (with isKeyPoint :33-54 and expandCluster :56-90), call sites FrmMain.cs:1507-1516,
+ * :2785-2786, BC/Tools.cs:591-592.  Exact semantics:
+ *   core[i]      <=> #{j : d(i,j) <= eps} >= min_pts (the count includes i)
+ *   expanding[i] <=> core[i] and not in_classed[i]
+ *   clusters      = connected components of the expanding points under d <= eps, numbered
+ *                   cf_in+1, cf_in+2, ... by increasing smallest member index
+ *   any other point within eps of an expanding point takes the LARGEST such cluster id
+ *                   (BC/DBImproved.cs:87 relabels unconditionally); otherwise it is untouched
+ * coords     [n*dim] doubles, point-major (x,y[,z]); dim 2 or 3; the 2-D metrics read x,y
+ * cf_in      DBImproved.cf before the call (FrmMain.cs:1509 presets it)
+ * in_mask    ifShown filter of BC/DB.cs:40,63,98 -- must be NULL (VCP_SIGNED_SUM_2D / masks are
+ *            the dead DB class: VCP_ERR_UNSUPPORTED on the GPU)
+ * in_classed NULL = nobody classed and labels start at 0 (what every caller sets up,
+ *            FrmMain.cs:1219-1223, :1512-1515); else Point3D.isClassed on entry and `labels`
+ *            is read as Point3D.clusterId on entry
+ * labels     [n] out (in/out with in_classed): Point3D.clusterId
+ * is_core    [n] out, may be NULL: isKeyPoint flags SET by this call (core and queried)
+ * is_classed [n] out, may be NULL: Point3D.isClassed after the call
+ * cf_out     DBImproved.cf / clusterAmount after the call
+ * dist_evals DBImproved.iritatorNum increment as a 64-bit count (BC/DBImproved.cs:12,19):
+ *            what the O(n^2) C# would have evaluated, not what the GPU evaluates
+ */
+int vcp_dbscan(vcp_ctx* ctx, const double* coords, int64_t n, int dim, int metric, double eps,
+               int min_pts, int32_t cf_in, const uint8_t* in_mask, const uint8_t* in_classed,
+               int32_t* labels, uint8_t* is_core, uint8_t* is_classed, int32_t* cf_out,
+               int64_t* dist_evals);
+/* Same with device pointers; cf_out / dist_evals stay host pointers (16 bytes read back). */
+int vcp_dbscan_dev(vcp_ctx* ctx, const double* d_coords, int64_t n, int dim, int metric, double eps,
+                   int min_pts, int32_t cf_in, const uint8_t* d_in_classed, int32_t* d_labels,
+                   uint8_t* d_is_core, uint8_t* d_is_classed, int32_t* cf_out, int64_t* dist_evals);
+
+/* -- block-partitioned DBSCAN ("v2.0 multithread") ----------------------------------------
+ * Replaces MainForm.getClusterFromMotor (FrmMain.cs:1214-1291: sort, first-block size, (lo,hi]
+ * rectangle blocks via Tools.getListByScale2 BC/Tools.cs:510-513), StartCode (:2782-2794: one
+ * DBImproved per block) and CompleteWork3 (:1442-1520: renumber, demote clusters of
+ * <= small_max points, one global DBImproved over all noise with cf preset).
+ * motor [n*2]; labels [n] by original index (0 = noise or dropped); block_of [n] may be NULL
+ * (-1 = in no block); merge_order [n] may be NULL: original indices in final clusForMerge
+ * order, *m_out entries.  block_lo/block_hi: this context clusters only blocks
+ * block_lo <= b < block_hi in step StartCode (multi-GPU sharding; 0,-1 = all). */
+int vcp_dbscan_blocks(vcp_ctx* ctx, const double* motor, int64_t n, double eps, int min_pts,
+                      int pts_in_cell, int small_max, int32_t* labels, int32_t* block_of,
+                      int64_t* merge_order, int64_t* m_out, int32_t* rows, int32_t* cols,
+                      int32_t* kept, int32_t* del_sum, int32_t* cluster_amount, int64_t* dist_evals);
+
+/* -- centroids ----------------------------------------------------------------------------
+ * Replaces Tools.GetClusList (BC/Tools.cs:162-195; also getClusterCenter :118-155): per cluster
+ * id 1..K the mean of (X,Y,Z) -> c3 [K*3] and of (motor_x,motor_y) -> c2 [K*2]; counts [K].
+ * xyz or motor may be NULL (then c3 / c2 is not written).  Empty clusters: count 0, NaN rows.
+ * Sums are fixed-order binary64 tree reductions (run-to-run deterministic; they differ from the
+ * C#'s sequential sum in the last bits -- tolerance 1e-12 relative). */
+int vcp_centroids(vcp_ctx* ctx, const double* xyz, const double* motor, const int32_t* labels,
+                  int64_t n, int32_t K, double* c3, double* c2, int64_t* counts);
+int vcp_centroids_dev(vcp_ctx* ctx, const double* d_xyz, const double* d_motor, const int32_t* d_labels,
+                      int64_t n, int32_t K, double* d_c3, double* d_c2, int64_t* d_counts);
+
+/* Replaces Tools.MergeIDByDistance (BC/Tools.cs:580-621): DBImproved(minPts 2, L1 on X,Y) over the
+ * K centroids; map_to[k] = cluster id the k-th centroid's cluster is merged into, 0 = none. */
+int vcp_merge_centroids(vcp_ctx* ctx, const double* cxy, const int32_t* ids, int32_t K, double thr,
+                        int32_t* map_to, int32_t* merge_count);
+/* Replaces Tools.refreshCensAndClusByDictionary (BC/Tools.cs:521-572): relabel points through
+ * map_by_id (index id-1, 0 = keep), renumber surviving ids 1..K' ascending, recompute centroids. */
+int vcp_refresh_by_dictionary(vcp_ctx* ctx, const double* xyz, const double* motor, int32_t* labels,
+                              int64_t n, int32_t K, const int32_t* map_by_id, int32_t* new_k,
+                              double* c3, double* c2, int64_t* counts);
+
+/* -- ICP ------------------------------------------------------------------------------------
+ * Replaces ICP.go_hell_ICP(model, data, R, T, e) (BC/ICP.cs:18-181): per round nearest model
+ * point per data point (FindClosestPointSet :224-250, lowest index on ties), the 16 sums
+ * (CalculateMeanPoint3D :255-273, sum p y^T :38-52, SSE :126-133), Horn's closed form on the
+ * host (the INTENDED arithmetic of :53-124; the as-written code is non-functional, SURVEY.md
+ * fact 4), composition R <- R1 R, T <- R1 T + T1 (:149-177), P <- R data + T (TransPoint
+ * :195-219).  model [nm*3], data [nd*3]; R [9] row-major and T [3] are outputs. */
+int vcp_icp(vcp_ctx* ctx, const double* model, int64_t nm, const double* data, int64_t nd, double tol,
+            int max_iter, int stop_rule, double R[9], double T[3], double* sse, double* rmse,
+            int32_t* iters);
+int vcp_icp_dev(vcp_ctx* ctx, const double* d_model, int64_t nm, const double* d_data, int64_t nd,
+                double tol, int max_iter, int stop_rule, double R[9], double T[3], double* sse,
+                double* rmse, int32_t* iters);
+/* One correspondence pass (A10+A11): sums[16] = sum p[3], sum y[3], sum p y^T[9], SSE for
+ * p = R data + T; nn [nd] may be NULL.  R,T NULL = identity. */
+int vcp_icp_sums(vcp_ctx* ctx, const double* model, int64_t nm, const double* data, int64_t nd,
+                 const double R[9], const double T[3], double sums[16], int32_t* nn);
+
+/* -- matching ------------------------------------------------------------------------------
+ * Replaces MainForm.calMatchedCoords (FrmMain.cs:3572-3587) + RecorrectMatchingPtsByDistance
+ * (:3588-3618, getDisP :829-835): matched = M * (c,1); nearest truth by Euclidean distance
+ * (strict <, lowest index on ties); is_matched iff distance < max_dist. */
+int vcp_match(vcp_ctx* ctx, const double* centers, int32_t K, const double* truths, int32_t T,
+              const double M[16], double max_dist, double* matched_xyz, uint8_t* is_matched,
+              int32_t* nearest, double* nearest_dist, int32_t* count_matched);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,243 @@
+"""ctypes binding of the CPU oracle (oracle/libvcp_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under vtkcloudpoint_amd/ may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libvcp_oracle.so")
+
+L1_2D, L2_2D, L2_3D, SIGNED_SUM_2D = 0, 1, 2, 3
+STOP_SSE_DELTA, STOP_RMSE = 0, 1
+OK, ERR_ARG, ERR_EMPTY, ERR_DEGENERATE, ERR_INDEX, ERR_TOO_LARGE = 0, -1, -2, -3, -4, -5
+
+
+def build():
+    src = [os.path.join(_HERE, f) for f in ("vcp_oracle.cpp", "vcp_oracle.h", "Makefile")]
+    if (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+    return _lib
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+def _f64(a, cols=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if cols is not None:
+        a = a.reshape(-1, cols)
+    return a
+
+
+class OracleError(RuntimeError):
+    def __init__(self, code):
+        super().__init__("oracle error %d" % code)
+        self.code = code
+
+
+def _chk(rc):
+    if rc != 0:
+        raise OracleError(rc)
+
+
+def _state(n, classed, labels, is_key):
+    classed = np.zeros(n, np.uint8) if classed is None else np.array(classed, np.uint8)
+    labels = np.zeros(n, np.int32) if labels is None else np.array(labels, np.int32)
+    is_key = np.zeros(n, np.uint8) if is_key is None else np.array(is_key, np.uint8)
+    return classed, labels, is_key
+
+
+def dbscan(coords, eps, min_pts, metric=L1_2D, cf_in=0, classed=None, labels=None, is_key=None,
+           literal=False, dedupe=False):
+    """Returns dict(labels, classed, is_key, cf, evals).  coords [n, dim]."""
+    coords = _f64(coords)
+    n, dim = coords.shape if coords.ndim == 2 else (0, 2)
+    classed, labels, is_key = _state(n, classed, labels, is_key)
+    cf = C.c_int32(0)
+    ev = C.c_int64(0)
+    if literal:
+        rc = lib().orc_dbscan_literal(_p(coords, C.c_double), C.c_int64(n), dim, metric, C.c_double(eps),
+                                      int(min_pts), C.c_int32(cf_in), _p(classed, C.c_uint8),
+                                      _p(labels, C.c_int32), _p(is_key, C.c_uint8), C.byref(cf),
+                                      C.byref(ev), int(dedupe))
+    else:
+        rc = lib().orc_dbscan_canonical(_p(coords, C.c_double), C.c_int64(n), dim, metric, C.c_double(eps),
+                                        int(min_pts), C.c_int32(cf_in), _p(classed, C.c_uint8),
+                                        _p(labels, C.c_int32), _p(is_key, C.c_uint8), C.byref(cf),
+                                        C.byref(ev))
+    _chk(rc)
+    return dict(labels=labels, classed=classed, is_key=is_key, cf=cf.value, evals=ev.value)
+
+
+def db_literal(coords, eps, min_pts, shown=None, classed=None, labels=None, is_key=None):
+    coords = _f64(coords)
+    n, dim = coords.shape
+    shown = np.ones(n, np.uint8) if shown is None else np.array(shown, np.uint8)
+    classed, labels, is_key = _state(n, classed, labels, is_key)
+    ca, pa, ev = C.c_int32(0), C.c_int32(0), C.c_int64(0)
+    _chk(lib().orc_db_literal(_p(coords, C.c_double), C.c_int64(n), dim, C.c_double(eps), int(min_pts),
+                              _p(shown, C.c_uint8), _p(classed, C.c_uint8), _p(labels, C.c_int32),
+                              _p(is_key, C.c_uint8), C.byref(ca), C.byref(pa), C.byref(ev)))
+    return dict(labels=labels, classed=classed, is_key=is_key, cluster_amount=ca.value,
+                points_amount=pa.value, evals=ev.value)
+
+
+def block_pipeline(motor, eps, min_pts, pts_in_cell, small_max=3, canonical=True, brute=False):
+    motor = _f64(motor, 2)
+    n = motor.shape[0]
+    labels = np.zeros(n, np.int32)
+    block_of = np.zeros(n, np.int32)
+    order = np.zeros(max(n, 1), np.int64)
+    m = C.c_int64(0)
+    rows, cols, kept, dels, ca = (C.c_int32(0) for _ in range(5))
+    ev = C.c_int64(0)
+    _chk(lib().orc_block_pipeline(_p(motor, C.c_double), C.c_int64(n), C.c_double(eps), int(min_pts),
+                                  int(pts_in_cell), int(small_max), int(canonical), int(brute),
+                                  _p(labels, C.c_int32), _p(block_of, C.c_int32), _p(order, C.c_int64),
+                                  C.byref(m), C.byref(rows), C.byref(cols), C.byref(kept),
+                                  C.byref(dels), C.byref(ca), C.byref(ev)))
+    return dict(labels=labels, block_of=block_of, order=order[: m.value].copy(), rows=rows.value,
+                cols=cols.value, kept=kept.value, del_sum=dels.value, cluster_amount=ca.value,
+                evals=ev.value)
+
+
+def centroids(xyz, motor, labels, K, order=None):
+    xyz = None if xyz is None else _f64(xyz, 3)
+    motor = None if motor is None else _f64(motor, 2)
+    labels = np.ascontiguousarray(labels, np.int32)
+    order = None if order is None else np.ascontiguousarray(order, np.int64)
+    m = len(labels) if order is None else len(order)
+    c3 = np.zeros((K, 3))
+    c2 = np.zeros((K, 2))
+    counts = np.zeros(K, np.int64)
+    _chk(lib().orc_centroids(_p(xyz, C.c_double), _p(motor, C.c_double), _p(labels, C.c_int32),
+                             _p(order, C.c_int64), C.c_int64(m), C.c_int32(K), _p(c3, C.c_double),
+                             _p(c2, C.c_double), _p(counts, C.c_int64)))
+    return c3, c2, counts
+
+
+def merge_ids(cxy, ids, thr):
+    cxy = _f64(cxy, 2)
+    ids = np.ascontiguousarray(ids, np.int32)
+    K = len(ids)
+    map_to = np.zeros(K, np.int32)
+    mc = C.c_int32(0)
+    _chk(lib().orc_merge_ids(_p(cxy, C.c_double), _p(ids, C.c_int32), C.c_int32(K), C.c_double(thr),
+                             _p(map_to, C.c_int32), C.byref(mc)))
+    return map_to, mc.value
+
+
+def refresh_by_dictionary(xyz, motor, labels, K, map_by_id, order=None):
+    xyz = _f64(xyz, 3)
+    motor = _f64(motor, 2)
+    labels = np.array(labels, np.int32)
+    map_by_id = np.ascontiguousarray(map_by_id, np.int32)
+    order = None if order is None else np.ascontiguousarray(order, np.int64)
+    m = len(labels) if order is None else len(order)
+    c3 = np.zeros((K, 3))
+    c2 = np.zeros((K, 2))
+    counts = np.zeros(K, np.int64)
+    nk = C.c_int32(0)
+    _chk(lib().orc_refresh_by_dictionary(_p(xyz, C.c_double), _p(motor, C.c_double), _p(labels, C.c_int32),
+                                         _p(order, C.c_int64), C.c_int64(m), C.c_int32(K),
+                                         _p(map_by_id, C.c_int32), C.byref(nk), _p(c3, C.c_double),
+                                         _p(c2, C.c_double), _p(counts, C.c_int64)))
+    k = nk.value
+    return labels, k, c3[:k], c2[:k], counts[:k]
+
+
+def find_closest(model, p):
+    model = _f64(model, 3)
+    p = _f64(p, 3)
+    idx = np.zeros(len(p), np.int32)
+    lib().orc_find_closest(_p(model, C.c_double), C.c_int64(len(model)), _p(p, C.c_double),
+                           C.c_int64(len(p)), _p(idx, C.c_int32))
+    return idx
+
+
+def trans_point(src, R, T):
+    src = _f64(src, 3)
+    R = _f64(R).reshape(9)
+    T = _f64(T).reshape(3)
+    dst = np.zeros_like(src)
+    lib().orc_trans_point(_p(src, C.c_double), C.c_int64(len(src)), _p(R, C.c_double), _p(T, C.c_double),
+                          _p(dst, C.c_double))
+    return dst
+
+
+def calc_rotation(q):
+    q = _f64(q).reshape(4)
+    R = np.zeros(9)
+    lib().orc_calc_rotation(_p(q, C.c_double), _p(R, C.c_double))
+    return R.reshape(3, 3)
+
+
+def icp_sums(model, p):
+    model = _f64(model, 3)
+    p = _f64(p, 3)
+    s = np.zeros(16)
+    lib().orc_icp_sums(_p(model, C.c_double), C.c_int64(len(model)), _p(p, C.c_double), C.c_int64(len(p)),
+                       _p(s, C.c_double))
+    return s
+
+
+def horn_from_sums(s, nd):
+    s = _f64(s).reshape(16)
+    R1 = np.zeros(9)
+    T1 = np.zeros(3)
+    _chk(lib().orc_horn_from_sums(_p(s, C.c_double), C.c_int64(nd), _p(R1, C.c_double), _p(T1, C.c_double)))
+    return R1.reshape(3, 3), T1
+
+
+def jacobi_sym(A):
+    A = np.array(A, np.float64)
+    n = A.shape[0]
+    ev = np.zeros(n)
+    V = np.zeros((n, n))
+    lib().orc_jacobi_sym(_p(A, C.c_double), n, _p(ev, C.c_double), _p(V, C.c_double), 64)
+    return ev, V
+
+
+def icp(model, data, tol=1e-4, max_iter=100, stop_rule=STOP_SSE_DELTA):
+    model = _f64(model, 3)
+    data = _f64(data, 3)
+    R = np.zeros(9)
+    T = np.zeros(3)
+    sse, rmse = C.c_double(0), C.c_double(0)
+    it = C.c_int32(0)
+    _chk(lib().orc_icp(_p(model, C.c_double), C.c_int64(len(model)), _p(data, C.c_double),
+                       C.c_int64(len(data)), C.c_double(tol), int(max_iter), int(stop_rule),
+                       _p(R, C.c_double), _p(T, C.c_double), C.byref(sse), C.byref(rmse), C.byref(it)))
+    return dict(R=R.reshape(3, 3), T=T, sse=sse.value, rmse=rmse.value, iters=it.value)
+
+
+def match(centers, truths, M, max_dist):
+    centers = _f64(centers, 3)
+    truths = _f64(truths, 3)
+    M = _f64(M).reshape(16)
+    K, T = len(centers), len(truths)
+    mxyz = np.zeros((K, 3))
+    is_m = np.zeros(K, np.uint8)
+    nearest = np.zeros(K, np.int32)
+    nd = np.zeros(K)
+    cnt = C.c_int32(0)
+    _chk(lib().orc_match(_p(centers, C.c_double), C.c_int32(K), _p(truths, C.c_double), C.c_int32(T),
+                         _p(M, C.c_double), C.c_double(max_dist), _p(mxyz, C.c_double), _p(is_m, C.c_uint8),
+                         _p(nearest, C.c_int32), _p(nd, C.c_double), C.byref(cnt)))
+    return dict(matched_xyz=mxyz, is_matched=is_m, nearest=nearest, nearest_dist=nd, count=cnt.value)

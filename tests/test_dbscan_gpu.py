@@ -1,0 +1,88 @@
+"""GPU parity: libvcp.so DBSCAN (through the C-ABI) vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from vtkcloudpoint_amd import _native as N
+from vtkcloudpoint_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(g, o, what=""):
+    assert np.array_equal(g["labels"], o["labels"]), what + " labels"
+    assert np.array_equal(g["is_classed"], o["classed"]), what + " classed"
+    assert g["cf"] == o["cf"], what + " cf"
+    assert g["evals"] == o["evals"], what + " evals"
+
+
+def test_random_small_with_ties(vcp_ctx, oracle):
+    rng = np.random.default_rng(7)
+    for trial in range(300):
+        n = int(rng.integers(1, 200))
+        metric = int(rng.integers(0, 3))
+        dim = 3 if metric == 2 else int(rng.integers(2, 4))
+        c = rng.integers(0, 12, size=(n, dim)).astype(np.float64) * 0.25
+        eps = float(rng.choice([0.25, 0.5, 0.75, 1.0, 0.0]))
+        mp = int(rng.integers(1, 7))
+        cf = int(rng.integers(0, 5))
+        if trial % 3 == 0:
+            cls = (rng.random(n) < 0.15).astype(np.uint8)
+            lab0 = (rng.integers(1, 4, n) * cls).astype(np.int32)
+        else:
+            cls, lab0 = None, None
+        o = oracle.dbscan(c, eps, mp, metric, cf, cls, lab0, literal=True)
+        g = vcp_ctx.dbscan(c, eps, mp, metric, cf, cls, lab0)
+        _same(g, o, "trial %d" % trial)
+        # is_core = isKeyPoint flags set by this call
+        assert np.array_equal(g["is_core"], o["is_key"]), "trial %d is_key" % trial
+
+
+def test_c1_both_metrics(vcp_ctx, oracle):
+    d = synth.config_c1()
+    o = oracle.dbscan(d["motor"], d["eps_l1"], d["min_pts"], N.L1_2D, literal=True)
+    g = vcp_ctx.dbscan(d["motor"], d["eps_l1"], d["min_pts"], N.L1_2D)
+    _same(g, o, "c1 L1")
+    o = oracle.dbscan(d["xyz"], d["eps_l2"], d["min_pts"], N.L2_3D, literal=True)
+    g = vcp_ctx.dbscan(d["xyz"], d["eps_l2"], d["min_pts"], N.L2_3D)
+    _same(g, o, "c1 L2_3D")
+
+
+def test_c2_1m(vcp_ctx, oracle):
+    d = synth.config_cloud(1_000_000)
+    o = oracle.dbscan(d["motor"], d["eps_l1"], d["min_pts"], N.L1_2D)
+    g = vcp_ctx.dbscan(d["motor"], d["eps_l1"], d["min_pts"], N.L1_2D)
+    _same(g, o, "c2 L1")
+    o = oracle.dbscan(d["xyz"], d["eps_l2"], d["min_pts"], N.L2_3D)
+    g = vcp_ctx.dbscan(d["xyz"], d["eps_l2"], d["min_pts"], N.L2_3D)
+    _same(g, o, "c2 L2_3D")
+
+
+def test_degenerate_and_edge_cases(vcp_ctx, oracle):
+    rng = np.random.default_rng(3)
+    c = rng.integers(0, 6, size=(50, 2)).astype(np.float64)
+    for eps, mp in [(-1.0, 0), (-1.0, 3), (0.5, 0), (0.5, -2), (float("nan"), 0), (float("inf"), 3), (0.0, 1)]:
+        o = oracle.dbscan(c, eps, mp, 0, 2, literal=True)
+        g = vcp_ctx.dbscan(c, eps, mp, 0, 2)
+        _same(g, o, "eps=%r mp=%r" % (eps, mp))
+    # empty input is a no-op (BaseClass/DBImproved.cs:93)
+    g = vcp_ctx.dbscan(np.zeros((0, 2)), 0.5, 3)
+    assert g["cf"] == 0 and g["evals"] == 0 and len(g["labels"]) == 0
+    # all points identical; non-finite coordinates never have neighbours
+    c = np.ones((300, 2))
+    _same(vcp_ctx.dbscan(c, 0.1, 5), oracle.dbscan(c, 0.1, 5, literal=True), "identical")
+    c = rng.random((200, 2))
+    c[5] = np.nan
+    c[17, 0] = np.inf
+    c[30, 1] = -np.inf
+    _same(vcp_ctx.dbscan(c, 0.2, 3), oracle.dbscan(c, 0.2, 3, literal=True), "nonfinite")
+    # unrepresentable eps and unquantised doubles
+    c = rng.random((3000, 3)) * 4
+    for metric in (0, 1, 2):
+        _same(vcp_ctx.dbscan(c, 0.1, 4, metric), oracle.dbscan(c, 0.1, 4, metric, literal=True), "raw doubles")
+
+
+def test_unsupported_dead_class(vcp_ctx):
+    c = np.zeros((4, 2))
+    with pytest.raises(N.VcpError) as e:
+        vcp_ctx.dbscan(c, 0.5, 2, N.SIGNED_SUM_2D)
+    assert e.value.code == -8

@@ -1,0 +1,64 @@
+"""GPU parity: libvcp.so ICP (through the C-ABI) vs the CPU oracle.  Tolerance 1e-5 on R, t, RMSE
+(BASELINE.json north_star); nearest-neighbour indices are bit-exact."""
+import numpy as np
+import pytest
+
+from vtkcloudpoint_amd import _native as N
+from vtkcloudpoint_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def test_nn_and_sums_bit_exact_indices(vcp_ctx, oracle):
+    d = synth.config_icp(nd=20000, nm=100, jitter=0.05)
+    sums, nn = vcp_ctx.icp_sums(d["model"], d["data"])
+    assert np.array_equal(nn, oracle.find_closest(d["model"], d["data"]))
+    ref = oracle.icp_sums(d["model"], d["data"])
+    assert np.allclose(sums, ref, rtol=1e-12, atol=1e-9)
+    # with a transform: P = R data + T first (TransPoint), same op order as the C#
+    R = synth.rotation_about((0, 1, 0), 3.0)
+    T = np.array([0.1, 0.2, -0.3])
+    sums, nn = vcp_ctx.icp_sums(d["model"], d["data"], R, T)
+    P = oracle.trans_point(d["data"], R, T)
+    assert np.array_equal(nn, oracle.find_closest(d["model"], P))
+    assert np.allclose(sums, oracle.icp_sums(d["model"], P), rtol=1e-12, atol=1e-9)
+
+
+def test_nn_tie_lowest_index(vcp_ctx, oracle):
+    model = np.array([[0.0, 0, 0], [2.0, 0, 0], [0.0, 2, 0], [2.0, 0, 0]])
+    data = np.array([[1.0, 0, 0], [1.0, 1.0, 0], [2.0, 0.0, 0.0], [5.0, 5.0, 5.0]])
+    _, nn = vcp_ctx.icp_sums(model, data)
+    assert nn.tolist() == [0, 0, 1, 1]
+    assert np.array_equal(nn, oracle.find_closest(model, data))
+
+
+@pytest.mark.parametrize("stop", [N.STOP_SSE_DELTA, N.STOP_RMSE])
+def test_icp_noise_free_recovers_transform(vcp_ctx, oracle, stop):
+    d = synth.config_icp(nd=50000, nm=100, jitter=0.0)
+    g = vcp_ctx.icp(d["model"], d["data"], 1e-4, 100, stop)
+    o = oracle.icp(d["model"], d["data"], 1e-4, 100, stop)
+    assert g["iters"] == o["iters"]
+    assert np.abs(g["R"] - o["R"]).max() < TOL and np.abs(g["T"] - o["T"]).max() < TOL
+    assert abs(g["rmse"] - o["rmse"]) < TOL
+    assert np.abs(g["R"] - d["R_true"]).max() < TOL and np.abs(g["T"] - d["T_true"]).max() < TOL
+    assert g["rmse"] < 1e-4
+
+
+def test_icp_c3_50_rounds(vcp_ctx, oracle):
+    """C3: 1M data points vs 100-pt model, 50 rounds fixed (tol 0 never stops early)."""
+    d = synth.config_icp(nd=1_000_000, nm=100, jitter=0.05)
+    g = vcp_ctx.icp(d["model"], d["data"], 0.0, 50, N.STOP_SSE_DELTA)
+    o = oracle.icp(d["model"], d["data"], 0.0, 50, N.STOP_SSE_DELTA)
+    assert g["iters"] == 50 and o["iters"] == 50
+    assert np.abs(g["R"] - o["R"]).max() < TOL and np.abs(g["T"] - o["T"]).max() < TOL
+    assert abs(g["rmse"] - o["rmse"]) < TOL and abs(g["sse"] - o["sse"]) < 1e-6 * o["sse"]
+
+
+def test_icp_errors(vcp_ctx):
+    with pytest.raises(N.VcpError) as e:
+        vcp_ctx.icp(np.zeros((0, 3)), np.zeros((5, 3)))
+    assert e.value.code == -2
+    # empty data: nothing to match, one round, R/T untouched (BaseClass/ICP.cs: loop body divides by 0)
+    g = vcp_ctx.icp(np.zeros((3, 3)), np.zeros((0, 3)))
+    assert g["iters"] == 1

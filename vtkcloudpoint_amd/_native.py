@@ -1,0 +1,176 @@
+"""ctypes binding of libvcp.so (include/vcp.h).  No CPU fallback: if the HIP library is missing or
+no GPU is present every compute call raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvcp.so")
+
+L1_2D, L2_2D, L2_3D, SIGNED_SUM_2D = 0, 1, 2, 3
+STOP_SSE_DELTA, STOP_RMSE = 0, 1
+
+STATUS = {
+    0: "VCP_OK", -1: "VCP_ERR_ARG", -2: "VCP_ERR_EMPTY", -3: "VCP_ERR_DEGENERATE", -4: "VCP_ERR_INDEX",
+    -5: "VCP_ERR_TOO_LARGE", -6: "VCP_ERR_NO_DEVICE", -7: "VCP_ERR_HIP", -8: "VCP_ERR_UNSUPPORTED",
+    -9: "VCP_ERR_NOMEM",
+}
+
+# every symbol include/vcp.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "vcp_create", "vcp_destroy", "vcp_last_error", "vcp_version", "vcp_set_stream", "vcp_dev_alloc",
+    "vcp_dev_free", "vcp_h2d", "vcp_d2h", "vcp_timing_enable", "vcp_timing_count", "vcp_timing_get",
+    "vcp_dbscan", "vcp_dbscan_dev", "vcp_dbscan_blocks", "vcp_centroids", "vcp_centroids_dev",
+    "vcp_merge_centroids", "vcp_refresh_by_dictionary", "vcp_icp", "vcp_icp_dev", "vcp_icp_sums",
+    "vcp_match",
+]
+
+
+class VcpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (STATUS.get(code, "?"), code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libvcp.so; raises if the HIP extension has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libvcp.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "or `make -C vtkcloudpoint_amd/csrc`")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.vcp_last_error.restype = C.c_char_p
+        _lib.vcp_last_error.argtypes = [C.c_void_p]
+        _lib.vcp_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        _lib.vcp_destroy.argtypes = [C.c_void_p]
+        _lib.vcp_destroy.restype = None
+    return _lib
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return C.c_void_p(a.ctypes.data)
+
+
+def _f64(a, cols=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if cols is not None:
+        a = a.reshape(-1, cols)
+    return a
+
+
+class Context:
+    """One vcp_ctx: one GPU, one stream.  Not thread-safe; create one per thread."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        rc = lib().vcp_create(int(device), C.byref(self._h))
+        if rc != 0:
+            raise VcpError(rc, (lib().vcp_last_error(None) or b"").decode())
+
+    def close(self):
+        if self._h:
+            lib().vcp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise VcpError(rc, (lib().vcp_last_error(self._h) or b"").decode())
+
+    # -- plumbing ------------------------------------------------------------------------------
+    def set_stream(self, stream_handle):
+        self._chk(lib().vcp_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def timing_enable(self, on=True):
+        self._chk(lib().vcp_timing_enable(self._h, int(on)))
+
+    def timing(self):
+        out = []
+        name = C.c_char_p()
+        ms = C.c_float()
+        for i in range(lib().vcp_timing_count(self._h)):
+            self._chk(lib().vcp_timing_get(self._h, i, C.byref(name), C.byref(ms)))
+            out.append((name.value.decode(), ms.value))
+        return out
+
+    # -- DBSCAN --------------------------------------------------------------------------------
+    def dbscan(self, coords, eps, min_pts, metric=L1_2D, cf_in=0, in_classed=None, labels=None,
+               in_mask=None):
+        """Host-buffer entry point.  Returns dict(labels, is_core, is_classed, cf, evals)."""
+        coords = _f64(coords)
+        if coords.ndim != 2:
+            coords = coords.reshape(0, 2)
+        n, dim = coords.shape
+        if in_classed is not None:
+            in_classed = np.ascontiguousarray(in_classed, np.uint8)
+            labels = np.array(labels if labels is not None else np.zeros(n), np.int32)
+        else:
+            labels = np.zeros(n, np.int32)
+        if in_mask is not None:
+            in_mask = np.ascontiguousarray(in_mask, np.uint8)
+        is_core = np.zeros(n, np.uint8)
+        is_classed = np.zeros(n, np.uint8)
+        cf = C.c_int32(0)
+        ev = C.c_int64(0)
+        self._chk(lib().vcp_dbscan(self._h, _ptr(coords), C.c_int64(n), int(dim), int(metric),
+                                   C.c_double(eps), int(min_pts), C.c_int32(cf_in), _ptr(in_mask),
+                                   _ptr(in_classed), _ptr(labels), _ptr(is_core), _ptr(is_classed),
+                                   C.byref(cf), C.byref(ev)))
+        return dict(labels=labels, is_core=is_core, is_classed=is_classed, cf=cf.value, evals=ev.value)
+
+    def dbscan_dev(self, d_coords, n, dim, eps, min_pts, metric=L1_2D, cf_in=0, d_in_classed=None,
+                   d_labels=None, d_is_core=None, d_is_classed=None):
+        """Device-pointer entry point (ints from tensor.data_ptr()).  Returns (cf, evals)."""
+        cf = C.c_int32(0)
+        ev = C.c_int64(0)
+        self._chk(lib().vcp_dbscan_dev(self._h, _ptr(d_coords), C.c_int64(n), int(dim), int(metric),
+                                       C.c_double(eps), int(min_pts), C.c_int32(cf_in), _ptr(d_in_classed),
+                                       _ptr(d_labels), _ptr(d_is_core), _ptr(d_is_classed), C.byref(cf),
+                                       C.byref(ev)))
+        return cf.value, ev.value
+
+    # -- ICP -----------------------------------------------------------------------------------
+    def icp(self, model, data, tol=1e-4, max_iter=100, stop_rule=STOP_SSE_DELTA):
+        model = _f64(model, 3)
+        data = _f64(data, 3)
+        R = np.zeros(9)
+        T = np.zeros(3)
+        sse, rmse, it = C.c_double(0), C.c_double(0), C.c_int32(0)
+        self._chk(lib().vcp_icp(self._h, _ptr(model), C.c_int64(len(model)), _ptr(data), C.c_int64(len(data)),
+                                C.c_double(tol), int(max_iter), int(stop_rule), _ptr(R), _ptr(T),
+                                C.byref(sse), C.byref(rmse), C.byref(it)))
+        return dict(R=R.reshape(3, 3), T=T, sse=sse.value, rmse=rmse.value, iters=it.value)
+
+    def icp_dev(self, d_model, nm, d_data, nd, tol=1e-4, max_iter=100, stop_rule=STOP_SSE_DELTA):
+        R = np.zeros(9)
+        T = np.zeros(3)
+        sse, rmse, it = C.c_double(0), C.c_double(0), C.c_int32(0)
+        self._chk(lib().vcp_icp_dev(self._h, _ptr(d_model), C.c_int64(nm), _ptr(d_data), C.c_int64(nd),
+                                    C.c_double(tol), int(max_iter), int(stop_rule), _ptr(R), _ptr(T),
+                                    C.byref(sse), C.byref(rmse), C.byref(it)))
+        return dict(R=R.reshape(3, 3), T=T, sse=sse.value, rmse=rmse.value, iters=it.value)
+
+    def icp_sums(self, model, data, R=None, T=None, want_nn=True):
+        model = _f64(model, 3)
+        data = _f64(data, 3)
+        R = None if R is None else _f64(R).reshape(9)
+        T = None if T is None else _f64(T).reshape(3)
+        sums = np.zeros(16)
+        nn = np.zeros(len(data), np.int32) if want_nn else None
+        self._chk(lib().vcp_icp_sums(self._h, _ptr(model), C.c_int64(len(model)), _ptr(data),
+                                     C.c_int64(len(data)), _ptr(R), _ptr(T), _ptr(sums), _ptr(nn)))
+        return sums, nn

@@ -1,0 +1,659 @@
+// dbscan.hip -- DBImproved.dbscan on MI355X (gfx950).
+//
+// Semantics: BaseClass/DBImproved.cs:14-114 in the order-free form of SURVEY.md 8a row A3 (see
+// include/vcp.h).  All distance arithmetic is binary64 with FMA contraction OFF, so the
+// `d <= eps` predicate is bit-identical to the C#'s (SSE2) evaluation; the grid only proposes
+// candidates and is conservative by construction (cell edge = eps * (1 + 2^-20)).
+//
+// Data layout in HBM (n points, sorted position p, original index i):
+//   cellcnt [ncells+1] u32   histogram, then exclusive scan = first sorted position of each cell
+//   cellof  [n] u32, rank [n] u32   cell id / arrival rank inside the cell, by original index
+//   sorted  [n*DIM] f64      coordinates in cell order (x-fastest linear cell id)
+//   sidx    [n] u32          original index of sorted position p
+//   flags   [n] u8           bit0 core, bit1 classed on entry, bit2 expanding
+//   parent  [n] u32          union-find over sorted positions (pointers only decrease)
+//   minord  [n] u32          per root: smallest original index in the component
+//   seedflag[n] u32          1 at the original index of each component's seed, then its scan
+//   rootcl  [n] i32          per root: final cluster id;  clseed [K] u32: seed index per cluster
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "vcp_ctx.hpp"
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr uint8_t F_CORE = 1, F_CLASSED = 2, F_EXPAND = 4;
+
+struct GridP {
+  double mn[3];
+  double inv_h;
+  int D[3];
+  int gdim;
+};
+
+struct PredP {
+  double thr;  // L1: eps; L2: largest s with sqrt(s) <= eps
+};
+
+template <int METRIC>
+__device__ __forceinline__ bool within(const double* a, const double* b, double thr) {
+  double dx = a[0] - b[0];
+  double dy = a[1] - b[1];
+  if (METRIC == VCP_L1_2D) {
+    return fabs(dx) + fabs(dy) <= thr;
+  } else if (METRIC == VCP_L2_2D) {
+    return dx * dx + dy * dy <= thr;
+  } else {
+    double dz = a[2] - b[2];
+    return dx * dx + dy * dy + dz * dz <= thr;
+  }
+}
+
+__device__ __forceinline__ int cell_coord(double x, double mn, double inv_h, int D) {
+  double u = (x - mn) * inv_h;
+  if (u >= 0.0 && u < (double)D) return (int)u;
+  if (u >= (double)D) return D - 1;
+  return 0;  // below the minimum or NaN
+}
+
+template <int DIM>
+__device__ __forceinline__ void load_pt(const double* __restrict__ c, int64_t i, double* q) {
+  if (DIM == 2) {
+    double2 v = *reinterpret_cast<const double2*>(c + 2 * i);
+    q[0] = v.x;
+    q[1] = v.y;
+  } else {
+    q[0] = c[3 * i];
+    q[1] = c[3 * i + 1];
+    q[2] = c[3 * i + 2];
+  }
+}
+
+// caller-order input: `stride` doubles per point, the metric reads the first GD of them
+template <int GD>
+__device__ __forceinline__ void load_in(const double* __restrict__ c, int64_t i, int stride, double* q) {
+  if (GD == 2 && stride == 2) {
+    double2 v = *reinterpret_cast<const double2*>(c + 2 * i);
+    q[0] = v.x;
+    q[1] = v.y;
+  } else {
+#pragma unroll
+    for (int a = 0; a < GD; a++) q[a] = c[i * stride + a];
+  }
+}
+
+// ---- bounds ---------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v = fmin(v, __shfl_down(v, d, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v = fmax(v, __shfl_down(v, d, 64));
+  return v;
+}
+
+// partial[b*6 + a] = min of axis a, partial[b*6 + 3 + a] = max, over finite values only
+template <int DIM>
+__global__ __launch_bounds__(TPB) void k_bounds(const double* __restrict__ c, int64_t n, int stride,
+                                               double* __restrict__ partial) {
+  double mn[3], mx[3];
+  for (int a = 0; a < 3; a++) {
+    mn[a] = INFINITY;
+    mx[a] = -INFINITY;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+#pragma unroll
+    for (int a = 0; a < DIM; a++) {
+      double v = c[i * stride + a];
+      if (isfinite(v)) {
+        mn[a] = fmin(mn[a], v);
+        mx[a] = fmax(mx[a], v);
+      }
+    }
+  }
+  __shared__ double sm[TPB / 64][6];
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    double lo = wave_min(mn[a]), hi = wave_max(mx[a]);
+    if (lane == 0) {
+      sm[w][a] = lo;
+      sm[w][3 + a] = hi;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double v = sm[0][threadIdx.x];
+    for (int k = 1; k < TPB / 64; k++)
+      v = threadIdx.x < 3 ? fmin(v, sm[k][threadIdx.x]) : fmax(v, sm[k][threadIdx.x]);
+    partial[blockIdx.x * 6 + threadIdx.x] = v;
+  }
+}
+
+__global__ void k_bounds_final(const double* __restrict__ partial, int nb, double* __restrict__ out) {
+  int a = threadIdx.x;
+  if (a >= 6) return;
+  double v = partial[a];
+  for (int b = 1; b < nb; b++) v = a < 3 ? fmin(v, partial[b * 6 + a]) : fmax(v, partial[b * 6 + a]);
+  out[a] = v;
+}
+
+// ---- grid build -------------------------------------------------------------------------------
+template <int DIM>
+__device__ __forceinline__ uint32_t cell_of(const double* q, const GridP& g, int* cc) {
+  cc[0] = cell_coord(q[0], g.mn[0], g.inv_h, g.D[0]);
+  cc[1] = cell_coord(q[1], g.mn[1], g.inv_h, g.D[1]);
+  uint32_t id = (uint32_t)cc[1] * (uint32_t)g.D[0] + (uint32_t)cc[0];
+  if (DIM == 3) {
+    cc[2] = cell_coord(q[2], g.mn[2], g.inv_h, g.D[2]);
+    id += (uint32_t)cc[2] * (uint32_t)g.D[0] * (uint32_t)g.D[1];
+  }
+  return id;
+}
+
+template <int DIM>
+__global__ __launch_bounds__(TPB) void k_cell_hist(const double* __restrict__ c, int64_t n, int stride, GridP g,
+                                                  uint32_t* __restrict__ cellcnt, uint32_t* __restrict__ cellof,
+                                                  uint32_t* __restrict__ rank) {
+  int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  double q[3];
+  int cc[3];
+  load_in<DIM>(c, i, stride, q);
+  uint32_t id = cell_of<DIM>(q, g, cc);
+  cellof[i] = id;
+  rank[i] = atomicAdd(&cellcnt[id], 1u);
+}
+
+template <int DIM>
+__global__ __launch_bounds__(TPB) void k_scatter(const double* __restrict__ c, int64_t n, int stride,
+                                                const uint32_t* __restrict__ cellstart,
+                                                const uint32_t* __restrict__ cellof,
+                                                const uint32_t* __restrict__ rank,
+                                                const uint8_t* __restrict__ in_classed,
+                                                double* __restrict__ sorted, uint32_t* __restrict__ sidx,
+                                                uint8_t* __restrict__ flags) {
+  int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  uint32_t p = cellstart[cellof[i]] + rank[i];
+  double q[3];
+  load_in<DIM>(c, i, stride, q);
+  if (DIM == 2) {
+    *reinterpret_cast<double2*>(sorted + 2 * (int64_t)p) = make_double2(q[0], q[1]);
+  } else {
+    sorted[3 * (int64_t)p] = q[0];
+    sorted[3 * (int64_t)p + 1] = q[1];
+    sorted[3 * (int64_t)p + 2] = q[2];
+  }
+  sidx[p] = (uint32_t)i;
+  flags[p] = (in_classed && in_classed[i]) ? F_CLASSED : 0;
+}
+
+// iterate the candidate rows of sorted position p: f(j) for every j in the 3 (9) x-rows of the
+// cell neighbourhood; f returns false to stop early.
+template <int DIM, class F>
+__device__ __forceinline__ void for_rows(const int* cc, const GridP& g, const uint32_t* __restrict__ cellstart, F&& f) {
+  int x0 = max(cc[0] - 1, 0), x1 = min(cc[0] + 1, g.D[0] - 1);
+  int y0 = max(cc[1] - 1, 0), y1 = min(cc[1] + 1, g.D[1] - 1);
+  int z0 = 0, z1 = 0;
+  if (DIM == 3) {
+    z0 = max(cc[2] - 1, 0);
+    z1 = min(cc[2] + 1, g.D[2] - 1);
+  }
+  for (int z = z0; z <= z1; z++)
+    for (int y = y0; y <= y1; y++) {
+      uint32_t base = ((DIM == 3 ? (uint32_t)z * (uint32_t)g.D[1] : 0u) + (uint32_t)y) * (uint32_t)g.D[0];
+      uint32_t s = cellstart[base + x0], e = cellstart[base + x1 + 1];
+      if (!f(s, e)) return;
+    }
+}
+
+// ---- core flags (region query with early exit at min_pts) ---------------------------------------
+template <int DIM, int METRIC>
+__global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted, int64_t n, GridP g, double thr,
+                                             int min_pts, const uint32_t* __restrict__ cellstart,
+                                             uint8_t* __restrict__ flags) {
+  int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (p >= n) return;
+  double q[3];
+  int cc[3];
+  load_pt<DIM>(sorted, p, q);
+  cell_of<DIM>(q, g, cc);
+  int cnt = 0;
+  for_rows<DIM>(cc, g, cellstart, [&](uint32_t s, uint32_t e) {
+    for (uint32_t j = s; j < e; j++) {
+      double r[3];
+      load_pt<DIM>(sorted, j, r);
+      if (within<METRIC>(q, r, thr)) {
+        if (++cnt >= min_pts) return false;
+      }
+    }
+    return true;
+  });
+  uint8_t fl = flags[p];
+  if (cnt >= min_pts) {
+    fl |= F_CORE;
+    if (!(fl & F_CLASSED)) fl |= F_EXPAND;
+  }
+  flags[p] = fl;
+}
+
+// ---- union-find over expanding points -------------------------------------------------------------
+__device__ __forceinline__ uint32_t ld_parent(const uint32_t* parent, uint32_t x) {
+  return __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint32_t uf_find(uint32_t* parent, uint32_t x) {
+  uint32_t p = ld_parent(parent, x);
+  while (p != x) {
+    uint32_t gp = ld_parent(parent, p);
+    if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // path halving
+    x = p;
+    p = gp;
+  }
+  return x;
+}
+
+// pointers always go from a larger to a smaller position, so the forest stays acyclic under any
+// interleaving; a stale read only ever shows an OLDER ancestor link, and the CAS is the arbiter.
+__device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t b) {
+  uint32_t ra = uf_find(parent, a), rb = uf_find(parent, b);
+  while (ra != rb) {
+    if (ra < rb) {
+      uint32_t t = ra;
+      ra = rb;
+      rb = t;
+    }
+    uint32_t old = atomicCAS(&parent[ra], ra, rb);
+    if (old == ra) return;
+    ra = uf_find(parent, old);
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_init_parent(uint32_t* __restrict__ parent, uint32_t* __restrict__ minord,
+                                                    int64_t n) {
+  int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (p >= n) return;
+  parent[p] = (uint32_t)p;
+  minord[p] = 0xFFFFFFFFu;
+}
+
+template <int DIM, int METRIC>
+__global__ __launch_bounds__(TPB) void k_union(const double* __restrict__ sorted, int64_t n, GridP g, double thr,
+                                              const uint32_t* __restrict__ cellstart,
+                                              const uint8_t* __restrict__ flags, uint32_t* __restrict__ parent) {
+  int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (p >= n) return;
+  if (!(flags[p] & F_EXPAND)) return;
+  double q[3];
+  int cc[3];
+  load_pt<DIM>(sorted, p, q);
+  cell_of<DIM>(q, g, cc);
+  const uint32_t me = (uint32_t)p;
+  for_rows<DIM>(cc, g, cellstart, [&](uint32_t s, uint32_t e) {
+    if (s >= me) return false;  // rows are visited in increasing position: nothing below me is left
+    if (e > me) e = me;         // every undirected edge is handled by its larger endpoint
+    for (uint32_t j = s; j < e; j++) {
+      if (!(flags[j] & F_EXPAND)) continue;
+      double r[3];
+      load_pt<DIM>(sorted, j, r);
+      if (within<METRIC>(q, r, thr)) uf_union(parent, me, j);
+    }
+    return true;
+  });
+}
+
+// flatten + smallest original index per component
+__global__ __launch_bounds__(TPB) void k_flatten(uint32_t* __restrict__ parent, const uint8_t* __restrict__ flags,
+                                                const uint32_t* __restrict__ sidx, uint32_t* __restrict__ minord,
+                                                int64_t n) {
+  int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (p >= n) return;
+  if (!(flags[p] & F_EXPAND)) return;
+  uint32_t r = (uint32_t)p;
+  uint32_t x = parent[r];
+  while (x != r) {
+    r = x;
+    x = parent[r];
+  }
+  parent[p] = r;  // roots keep pointing at themselves, so concurrent flattening is safe
+  atomicMin(&minord[r], sidx[p]);
+}
+
+__global__ __launch_bounds__(TPB) void k_seedflag(const uint32_t* __restrict__ parent, const uint8_t* __restrict__ flags,
+                                                 const uint32_t* __restrict__ minord, uint32_t* __restrict__ seedflag,
+                                                 int64_t n) {
+  int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (p >= n) return;
+  if ((flags[p] & F_EXPAND) && parent[p] == (uint32_t)p) seedflag[minord[p]] = 1u;
+}
+
+__global__ __launch_bounds__(TPB) void k_rootid(const uint32_t* __restrict__ parent, const uint8_t* __restrict__ flags,
+                                               const uint32_t* __restrict__ minord, const uint32_t* __restrict__ seedrank,
+                                               int32_t cf_in, int32_t* __restrict__ rootcl, uint32_t* __restrict__ clseed,
+                                               int64_t n) {
+  int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (p >= n) return;
+  if ((flags[p] & F_EXPAND) && parent[p] == (uint32_t)p) {
+    uint32_t k = seedrank[minord[p]];
+    rootcl[p] = cf_in + 1 + (int32_t)k;
+    clseed[k] = minord[p];
+  }
+}
+
+// ---- final labels, border rule, outputs in caller order, op counter ----------------------------
+// counters[0] = points not classed on entry, counters[1] = border points queried twice
+template <int DIM, int METRIC>
+__global__ __launch_bounds__(TPB) void k_label(const double* __restrict__ sorted, int64_t n, GridP g, double thr,
+                                              const uint32_t* __restrict__ cellstart, const uint8_t* __restrict__ flags,
+                                              const uint32_t* __restrict__ parent, const uint32_t* __restrict__ sidx,
+                                              const int32_t* __restrict__ rootcl, const uint32_t* __restrict__ clseed,
+                                              int32_t cf_in, int fresh, int32_t* __restrict__ labels,
+                                              uint8_t* __restrict__ is_core, uint8_t* __restrict__ is_classed,
+                                              unsigned long long* __restrict__ counters) {
+  int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  unsigned unclassed = 0, twice = 0;
+  if (p < n) {
+    uint8_t fl = flags[p];
+    uint32_t orig = sidx[p];
+    int32_t lab = 0;
+    if (fl & F_EXPAND) {
+      lab = rootcl[parent[p]];
+    } else {
+      double q[3];
+      int cc[3];
+      load_pt<DIM>(sorted, p, q);
+      cell_of<DIM>(q, g, cc);
+      int32_t mx = 0, mnid = 0x7FFFFFFF;
+      for_rows<DIM>(cc, g, cellstart, [&](uint32_t s, uint32_t e) {
+        for (uint32_t j = s; j < e; j++) {
+          if (!(flags[j] & F_EXPAND)) continue;
+          double r[3];
+          load_pt<DIM>(sorted, j, r);
+          if (within<METRIC>(q, r, thr)) {
+            int32_t id = rootcl[parent[j]];
+            mx = max(mx, id);
+            mnid = min(mnid, id);
+          }
+        }
+        return true;
+      });
+      lab = mx;
+      // reached first by cluster mnid; the C# main loop had already queried it once iff it sits
+      // before that cluster's seed (BaseClass/DBImproved.cs:93-104 then :63-67)
+      if (mx != 0 && !(fl & F_CLASSED) && orig < clseed[mnid - cf_in - 1]) twice = 1;
+    }
+    if (!(fl & F_CLASSED)) unclassed = 1;
+    if (lab != 0 || fresh) labels[orig] = lab;
+    if (is_core) is_core[orig] = ((fl & F_CORE) && !(fl & F_CLASSED)) ? 1 : 0;
+    if (is_classed) is_classed[orig] = ((fl & F_CLASSED) || lab != 0) ? 1 : 0;
+  }
+  // wave-level reduction, one atomic per wave
+  unsigned long long m1 = __ballot(unclassed), m2 = __ballot(twice);
+  if ((threadIdx.x & 63) == 0) {
+    if (m1) atomicAdd(&counters[0], (unsigned long long)__popcll(m1));
+    if (m2) atomicAdd(&counters[1], (unsigned long long)__popcll(m2));
+  }
+}
+
+// ---- eps < 0 or NaN: nobody has a neighbour, not even itself ---------------------------------------
+__global__ __launch_bounds__(TPB) void k_unclassed_flag(const uint8_t* __restrict__ in_classed, uint32_t* __restrict__ f,
+                                                       int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) f[i] = (in_classed && in_classed[i]) ? 0u : 1u;
+}
+__global__ __launch_bounds__(TPB) void k_degenerate(const uint8_t* __restrict__ in_classed, const uint32_t* __restrict__ rk,
+                                                   int64_t n, int32_t cf_in, int all_core, int fresh,
+                                                   int32_t* __restrict__ labels, uint8_t* __restrict__ is_core,
+                                                   uint8_t* __restrict__ is_classed) {
+  int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  bool cls = in_classed && in_classed[i];
+  if (!cls && all_core) labels[i] = cf_in + 1 + (int32_t)rk[i];
+  else if (fresh) labels[i] = 0;
+  if (is_core) is_core[i] = (!cls && all_core) ? 1 : 0;
+  if (is_classed) is_classed[i] = cls ? 1 : 0;  // expandCluster never marks the seed itself
+}
+
+// largest binary64 s such that sqrt(s) <= eps (sqrt is correctly rounded and monotone), so that
+// `sqrt(s) <= eps` can be tested as `s <= thr` without a device sqrt.
+double l2_threshold(double eps) {
+  if (std::isinf(eps)) return eps;
+  double t = eps * eps;
+  if (std::isinf(t)) t = std::numeric_limits<double>::max();
+  while (std::sqrt(t) > eps) t = std::nextafter(t, 0.0);
+  for (;;) {
+    double u = std::nextafter(t, std::numeric_limits<double>::infinity());
+    if (std::isinf(u) || std::sqrt(u) > eps) break;
+    t = u;
+  }
+  return t;
+}
+
+// DIM = dimension of the metric (grid and sorted copy); `stride` = doubles per input point
+template <int DIM, int METRIC>
+int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, double eps, int min_pts, int32_t cf_in,
+               const uint8_t* d_in_classed, int32_t* d_labels, uint8_t* d_is_core, uint8_t* d_is_classed,
+               int32_t* cf_out, int64_t* dist_evals) {
+  hipStream_t st = ctx->stream;
+  const unsigned nb = vcp_blocks(n, TPB);
+  const int fresh = d_in_classed == nullptr;
+
+  // 1. bounds over finite coordinates
+  vcp_phase(ctx, "bounds");
+  const int rb = (int)vcp_blocks(n, TPB, 1024);
+  VCP_TRY(vcp_ensure(ctx, ctx->b_misc, (size_t)(rb * 6 + 16) * sizeof(double)));
+  double* d_part = ctx->b_misc.as<double>();
+  double* d_bounds = d_part + (size_t)rb * 6;
+  hipLaunchKernelGGL((k_bounds<DIM>), dim3(rb), dim3(TPB), 0, st, d_coords, n, stride, d_part);
+  hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(64), 0, st, d_part, rb, d_bounds);
+  double* h = reinterpret_cast<double*>(ctx->pinned);
+  VCP_HIP(ctx, hipMemcpyAsync(h, d_bounds, 6 * sizeof(double), hipMemcpyDeviceToHost, st));
+  VCP_HIP(ctx, hipStreamSynchronize(st));
+
+  // 2. grid geometry (host): cell edge a hair above eps; coarsen until the cell count fits
+  GridP g;
+  g.gdim = DIM;
+  double range = 0.0;
+  for (int a = 0; a < 3; a++) {
+    double lo = a < DIM ? h[a] : 0.0, hi = a < DIM ? h[3 + a] : 0.0;
+    if (!(hi >= lo)) lo = hi = 0.0;  // no finite value on this axis
+    g.mn[a] = lo;
+    h[a] = lo;
+    h[3 + a] = hi;
+    range = std::fmax(range, hi - lo);
+  }
+  double cellw = eps * (1.0 + 1.0 / 1048576.0);
+  const double min_w = range / 1048575.0;
+  if (!(cellw >= min_w)) cellw = min_w;
+  if (!(cellw > 0.0)) cellw = 1.0;
+  int64_t budget = n * 32;
+  if (budget < (1 << 16)) budget = 1 << 16;
+  if (budget > ((int64_t)1 << 28)) budget = (int64_t)1 << 28;
+  int64_t ncells = 0;
+  for (int it = 0; it < 200; it++) {
+    ncells = 1;
+    for (int a = 0; a < 3; a++) {
+      double ext = a < DIM ? (h[3 + a] - h[a]) / cellw : 0.0;
+      int64_t d = std::isfinite(ext) ? (int64_t)ext + 1 : 1;
+      if (d > 1048576) d = 1048576;
+      g.D[a] = (int)d;
+      ncells *= d;
+    }
+    if (ncells <= budget || std::isinf(cellw)) break;
+    cellw *= 1.25;
+  }
+  if (ncells > budget) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "grid does not fit the cell budget");
+  g.inv_h = std::isinf(cellw) ? 0.0 : 1.0 / cellw;
+  const double thr = (METRIC == VCP_L1_2D) ? eps : l2_threshold(eps);
+
+  // 3. histogram + ranks, scan, scatter
+  vcp_phase(ctx, "cell_hist");
+  VCP_TRY(vcp_ensure(ctx, ctx->b_cellcnt, (size_t)(ncells + 2) * 4));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_cellof, (size_t)n * 4));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_rank, (size_t)n * 4));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_sorted, (size_t)n * DIM * 8));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_sidx, (size_t)n * 4));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_flags, (size_t)n));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_parent, (size_t)n * 4));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_minord, (size_t)n * 4));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_seedflag, (size_t)(n + 2) * 4));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_rootcl, (size_t)n * 4));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_clseed, (size_t)n * 4));
+  uint32_t* cellcnt = ctx->b_cellcnt.as<uint32_t>();
+  uint32_t* cellof = ctx->b_cellof.as<uint32_t>();
+  uint32_t* rank = ctx->b_rank.as<uint32_t>();
+  double* sorted = ctx->b_sorted.as<double>();
+  uint32_t* sidx = ctx->b_sidx.as<uint32_t>();
+  uint8_t* flags = ctx->b_flags.as<uint8_t>();
+  uint32_t* parent = ctx->b_parent.as<uint32_t>();
+  uint32_t* minord = ctx->b_minord.as<uint32_t>();
+  uint32_t* seedflag = ctx->b_seedflag.as<uint32_t>();
+  int32_t* rootcl = ctx->b_rootcl.as<int32_t>();
+  uint32_t* clseed = ctx->b_clseed.as<uint32_t>();
+  unsigned long long* counters = reinterpret_cast<unsigned long long*>(d_bounds + 8);
+
+  VCP_HIP(ctx, hipMemsetAsync(cellcnt, 0, (size_t)(ncells + 1) * 4, st));
+  hipLaunchKernelGGL((k_cell_hist<DIM>), dim3(nb), dim3(TPB), 0, st, d_coords, n, stride, g, cellcnt, cellof, rank);
+  vcp_phase(ctx, "cell_scan");
+  VCP_TRY(vcp_exclusive_scan_u32(ctx, cellcnt, cellcnt, ncells + 1, nullptr));
+  vcp_phase(ctx, "scatter");
+  hipLaunchKernelGGL((k_scatter<DIM>), dim3(nb), dim3(TPB), 0, st, d_coords, n, stride, cellcnt, cellof, rank,
+                     d_in_classed, sorted, sidx, flags);
+
+  // 4. core flags
+  vcp_phase(ctx, "core_count");
+  hipLaunchKernelGGL((k_core<DIM, METRIC>), dim3(nb), dim3(TPB), 0, st, sorted, n, g, thr, min_pts, cellcnt, flags);
+
+  // 5. components of the expanding points
+  vcp_phase(ctx, "union");
+  hipLaunchKernelGGL(k_init_parent, dim3(nb), dim3(TPB), 0, st, parent, minord, n);
+  VCP_HIP(ctx, hipMemsetAsync(seedflag, 0, (size_t)(n + 1) * 4, st));
+  VCP_HIP(ctx, hipMemsetAsync(counters, 0, 4 * sizeof(unsigned long long), st));
+  hipLaunchKernelGGL((k_union<DIM, METRIC>), dim3(nb), dim3(TPB), 0, st, sorted, n, g, thr, cellcnt, flags, parent);
+  vcp_phase(ctx, "flatten_number");
+  hipLaunchKernelGGL(k_flatten, dim3(nb), dim3(TPB), 0, st, parent, flags, sidx, minord, n);
+  hipLaunchKernelGGL(k_seedflag, dim3(nb), dim3(TPB), 0, st, parent, flags, minord, seedflag, n);
+  uint32_t* d_total = reinterpret_cast<uint32_t*>(counters + 2);
+  VCP_TRY(vcp_exclusive_scan_u32(ctx, seedflag, seedflag, n, d_total));
+  hipLaunchKernelGGL(k_rootid, dim3(nb), dim3(TPB), 0, st, parent, flags, minord, seedflag, cf_in, rootcl, clseed, n);
+
+  // 6. labels / border rule / outputs
+  vcp_phase(ctx, "label");
+  hipLaunchKernelGGL((k_label<DIM, METRIC>), dim3(nb), dim3(TPB), 0, st, sorted, n, g, thr, cellcnt, flags, parent,
+                     sidx, rootcl, clseed, cf_in, fresh, d_labels, d_is_core, d_is_classed, counters);
+  VCP_HIP(ctx, hipGetLastError());
+  unsigned long long* hc = reinterpret_cast<unsigned long long*>(ctx->pinned) + 8;
+  VCP_HIP(ctx, hipMemcpyAsync(hc, counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  VCP_TRY(vcp_phase_finish(ctx));
+  VCP_HIP(ctx, hipStreamSynchronize(st));
+  uint32_t K = *reinterpret_cast<uint32_t*>(hc + 2);
+  if (cf_out) *cf_out = cf_in + (int32_t)K;
+  if (dist_evals) *dist_evals = (int64_t)(hc[0] + hc[1] + K) * n;
+  return VCP_OK;
+}
+
+int run_degenerate(vcp_ctx* ctx, int64_t n, int min_pts, int32_t cf_in, const uint8_t* d_in_classed,
+                   int32_t* d_labels, uint8_t* d_is_core, uint8_t* d_is_classed, int32_t* cf_out,
+                   int64_t* dist_evals) {
+  hipStream_t st = ctx->stream;
+  const unsigned nb = vcp_blocks(n, TPB);
+  vcp_phase(ctx, "degenerate");
+  VCP_TRY(vcp_ensure(ctx, ctx->b_seedflag, (size_t)(n + 2) * 4));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_misc, 64));
+  uint32_t* f = ctx->b_seedflag.as<uint32_t>();
+  uint32_t* d_total = ctx->b_misc.as<uint32_t>();
+  hipLaunchKernelGGL(k_unclassed_flag, dim3(nb), dim3(TPB), 0, st, d_in_classed, f, n);
+  VCP_TRY(vcp_exclusive_scan_u32(ctx, f, f, n, d_total));
+  const int all_core = 0 >= min_pts;  // tmpList.Count (0) >= minPts, BaseClass/DBImproved.cs:105
+  hipLaunchKernelGGL(k_degenerate, dim3(nb), dim3(TPB), 0, st, d_in_classed, f, n, cf_in, all_core,
+                     d_in_classed == nullptr, d_labels, d_is_core, d_is_classed);
+  VCP_HIP(ctx, hipGetLastError());
+  uint32_t* hu = reinterpret_cast<uint32_t*>(ctx->pinned);
+  VCP_HIP(ctx, hipMemcpyAsync(hu, d_total, 4, hipMemcpyDeviceToHost, st));
+  VCP_TRY(vcp_phase_finish(ctx));
+  VCP_HIP(ctx, hipStreamSynchronize(st));
+  if (cf_out) *cf_out = cf_in + (all_core ? (int32_t)hu[0] : 0);
+  if (dist_evals) *dist_evals = (int64_t)hu[0] * n;
+  return VCP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vcp_dbscan_dev(vcp_ctx* ctx, const double* d_coords, int64_t n, int dim, int metric, double eps,
+                   int min_pts, int32_t cf_in, const uint8_t* d_in_classed, int32_t* d_labels,
+                   uint8_t* d_is_core, uint8_t* d_is_classed, int32_t* cf_out, int64_t* dist_evals) {
+  if (!ctx) return VCP_ERR_ARG;
+  if (n < 0) return vcp_fail(ctx, VCP_ERR_ARG, "n < 0");
+  if (dim != 2 && dim != 3) return vcp_fail(ctx, VCP_ERR_ARG, "dim must be 2 or 3");
+  if (metric == VCP_SIGNED_SUM_2D)
+    return vcp_fail(ctx, VCP_ERR_UNSUPPORTED,
+                    "VCP_SIGNED_SUM_2D is the dead DB class (BaseClass/DB.cs:21, FrmMain.cs:38); not built for the GPU");
+  if (metric < 0 || metric > 3) return vcp_fail(ctx, VCP_ERR_ARG, "unknown metric %d", metric);
+  if (metric == VCP_L2_3D && dim != 3) return vcp_fail(ctx, VCP_ERR_ARG, "VCP_L2_3D needs dim 3");
+  if (n >= 0x7FFFFFF0LL) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "n beyond 32-bit indexing");
+  if (n > 0 && (!d_coords || !d_labels)) return vcp_fail(ctx, VCP_ERR_ARG, "null buffer");
+  VCP_TRY(vcp_bind(ctx));
+  vcp_phase_reset(ctx);
+  if (n == 0) {
+    if (cf_out) *cf_out = cf_in;
+    if (dist_evals) *dist_evals = 0;
+    ctx->last_timing.clear();
+    return VCP_OK;
+  }
+  if (!(eps >= 0.0))
+    return run_degenerate(ctx, n, min_pts, cf_in, d_in_classed, d_labels, d_is_core, d_is_classed, cf_out, dist_evals);
+#define VCP_RUN(D, M)                                                                                         \
+  return run_dbscan<D, M>(ctx, d_coords, n, dim, eps, min_pts, cf_in, d_in_classed, d_labels, d_is_core, \
+                          d_is_classed, cf_out, dist_evals)
+  if (metric == VCP_L1_2D) VCP_RUN(2, VCP_L1_2D);
+  if (metric == VCP_L2_2D) VCP_RUN(2, VCP_L2_2D);
+  VCP_RUN(3, VCP_L2_3D);
+#undef VCP_RUN
+}
+
+int vcp_dbscan(vcp_ctx* ctx, const double* coords, int64_t n, int dim, int metric, double eps, int min_pts,
+               int32_t cf_in, const uint8_t* in_mask, const uint8_t* in_classed, int32_t* labels,
+               uint8_t* is_core, uint8_t* is_classed, int32_t* cf_out, int64_t* dist_evals) {
+  if (!ctx) return VCP_ERR_ARG;
+  if (in_mask)
+    return vcp_fail(ctx, VCP_ERR_UNSUPPORTED,
+                    "ifShown masks belong to the dead DB class (BaseClass/DB.cs:40); not built for the GPU");
+  if (n < 0) return vcp_fail(ctx, VCP_ERR_ARG, "n < 0");
+  if (dim != 2 && dim != 3) return vcp_fail(ctx, VCP_ERR_ARG, "dim must be 2 or 3");
+  if (n > 0 && (!coords || !labels)) return vcp_fail(ctx, VCP_ERR_ARG, "null buffer");
+  VCP_TRY(vcp_bind(ctx));
+  hipStream_t st = ctx->stream;
+  size_t nn = (size_t)(n > 0 ? n : 1);
+  VCP_TRY(vcp_ensure(ctx, ctx->b_in0, nn * dim * 8));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_in1, nn));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_out0, nn * 4));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_out1, nn));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_out2, nn));
+  if (n > 0) {
+    VCP_HIP(ctx, hipMemcpyAsync(ctx->b_in0.p, coords, (size_t)n * dim * 8, hipMemcpyHostToDevice, st));
+    if (in_classed) {
+      VCP_HIP(ctx, hipMemcpyAsync(ctx->b_in1.p, in_classed, (size_t)n, hipMemcpyHostToDevice, st));
+      VCP_HIP(ctx, hipMemcpyAsync(ctx->b_out0.p, labels, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    }
+  }
+  int rc = vcp_dbscan_dev(ctx, ctx->b_in0.as<double>(), n, dim, metric, eps, min_pts, cf_in,
+                          in_classed ? ctx->b_in1.as<uint8_t>() : nullptr, ctx->b_out0.as<int32_t>(),
+                          ctx->b_out1.as<uint8_t>(), ctx->b_out2.as<uint8_t>(), cf_out, dist_evals);
+  if (rc != VCP_OK) return rc;
+  if (n > 0) {
+    VCP_HIP(ctx, hipMemcpyAsync(labels, ctx->b_out0.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    if (is_core) VCP_HIP(ctx, hipMemcpyAsync(is_core, ctx->b_out1.p, (size_t)n, hipMemcpyDeviceToHost, st));
+    if (is_classed) VCP_HIP(ctx, hipMemcpyAsync(is_classed, ctx->b_out2.p, (size_t)n, hipMemcpyDeviceToHost, st));
+    VCP_HIP(ctx, hipStreamSynchronize(st));
+  }
+  return VCP_OK;
+}
+
+}  // extern "C"

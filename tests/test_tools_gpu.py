@@ -1,0 +1,87 @@
+"""GPU parity for the Tools part of the path (centroids, centroid merge, dictionary refresh) and the
+centroid<->truth matching, through the C-ABI, vs the CPU oracle."""
+import numpy as np
+import pytest
+
+from vtkcloudpoint_amd import _native as N
+from vtkcloudpoint_amd import synth
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-12  # fixed-order tree sum vs the C#'s sequential sum
+
+
+def test_centroids_c1_and_1m(vcp_ctx, oracle):
+    for d in (synth.config_c1(), synth.config_cloud(1_000_000)):
+        o = oracle.dbscan(d["motor"], d["eps_l1"], d["min_pts"])
+        K = o["cf"]
+        c3, c2, cnt = vcp_ctx.centroids(d["xyz"], d["motor"], o["labels"], K)
+        r3, r2, rc = oracle.centroids(d["xyz"], d["motor"], o["labels"], K)
+        assert np.array_equal(cnt, rc)
+        assert np.allclose(c3, r3, rtol=RTOL, atol=1e-12) and np.allclose(c2, r2, rtol=RTOL, atol=1e-12)
+        # run-to-run deterministic (fixed reduction tree)
+        c3b, c2b, _ = vcp_ctx.centroids(d["xyz"], d["motor"], o["labels"], K)
+        assert np.array_equal(c3, c3b) and np.array_equal(c2, c2b)
+
+
+def test_centroids_edge_cases(vcp_ctx, oracle):
+    rng = np.random.default_rng(5)
+    n = 5000
+    xyz = rng.random((n, 3))
+    motor = rng.random((n, 2))
+    lab = rng.integers(0, 8, n).astype(np.int32)
+    lab[lab == 3] = 0  # cluster 3 empty -> NaN row, count 0 (Tools.cs:191 skips it)
+    c3, c2, cnt = vcp_ctx.centroids(xyz, motor, lab, 9)
+    r3, r2, rc = oracle.centroids(xyz, motor, lab, 9)
+    assert np.array_equal(cnt, rc) and cnt[2] == 0 and cnt[8] == 0
+    assert np.allclose(c3, r3, rtol=RTOL, equal_nan=True) and np.allclose(c2, r2, rtol=RTOL, equal_nan=True)
+    # a giant cluster spanning many chunks and all-noise input
+    lab[:] = 1
+    c3, _, cnt = vcp_ctx.centroids(xyz, None, lab, 1)
+    assert cnt[0] == n and np.allclose(c3[0], xyz.mean(0), rtol=1e-12)
+    lab[:] = 0
+    _, _, cnt = vcp_ctx.centroids(xyz, motor, lab, 4)
+    assert cnt.sum() == 0
+    # label beyond K -> the C# indexes clusList out of range
+    lab[7] = 5
+    with pytest.raises(N.VcpError) as e:
+        vcp_ctx.centroids(xyz, motor, lab, 4)
+    assert e.value.code == -4
+
+
+def test_merge_and_refresh(vcp_ctx, oracle):
+    d = synth.config_cloud(200_000, seed=9)
+    o = oracle.dbscan(d["motor"], d["eps_l1"], d["min_pts"])
+    K = o["cf"]
+    r3, r2, rc = oracle.centroids(d["xyz"], d["motor"], o["labels"], K)
+    ids = np.arange(1, K + 1, dtype=np.int32)
+    for thr in (0.1, 0.5, 2.0):
+        mo, co = oracle.merge_ids(r3[:, :2], ids, thr)
+        mg, cg = vcp_ctx.merge_centroids(r3[:, :2], ids, thr)
+        assert np.array_equal(mo, mg) and co == cg
+        lo, ko, o3, o2, oc = oracle.refresh_by_dictionary(d["xyz"], d["motor"], o["labels"], K, mo)
+        lg, kg, g3, g2, gc = vcp_ctx.refresh_by_dictionary(d["xyz"], d["motor"], o["labels"], K, mg)
+        assert ko == kg and np.array_equal(lo, lg) and np.array_equal(oc, gc)
+        assert np.allclose(o3, g3, rtol=RTOL, atol=1e-12) and np.allclose(o2, g2, rtol=RTOL, atol=1e-12)
+    assert co > 0  # the largest threshold really merges something
+
+
+def test_match(vcp_ctx, oracle):
+    rng = np.random.default_rng(11)
+    K, T = 3000, 257
+    truths = rng.random((T, 3)) * 100
+    centers = rng.random((K, 3)) * 100
+    # exact ties: duplicate truth points (lowest index must win) and centroids sitting on truths
+    truths[100] = truths[7]
+    centers[:50] = truths[:50]
+    M = np.eye(4)
+    M[:3, :3] = synth.rotation_about((0, 0, 1), 2.0)
+    M[:3, 3] = (0.5, -0.25, 0.125)
+    o = oracle.match(centers, truths, M, 5.0)
+    g = vcp_ctx.match(centers, truths, M, 5.0)
+    assert np.array_equal(o["matched_xyz"], g["matched_xyz"])
+    assert np.array_equal(o["nearest"], g["nearest"])
+    assert np.array_equal(o["nearest_dist"], g["nearest_dist"])  # correctly rounded sqrt on both sides
+    assert np.array_equal(o["is_matched"], g["is_matched"]) and o["count"] == g["count"]
+    with pytest.raises(N.VcpError) as e:
+        vcp_ctx.match(centers, np.zeros((0, 3)), M, 5.0)
+    assert e.value.code == -2

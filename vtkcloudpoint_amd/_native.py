@@ -174,3 +174,56 @@ class Context:
         self._chk(lib().vcp_icp_sums(self._h, _ptr(model), C.c_int64(len(model)), _ptr(data),
                                      C.c_int64(len(data)), _ptr(R), _ptr(T), _ptr(sums), _ptr(nn)))
         return sums, nn
+
+    # -- centroids / merge / match -----------------------------------------------------------------
+    def centroids(self, xyz, motor, labels, K):
+        """Tools.GetClusList: returns (c3 [K,3], c2 [K,2], counts [K]); empty clusters are NaN rows."""
+        xyz = None if xyz is None else _f64(xyz, 3)
+        motor = None if motor is None else _f64(motor, 2)
+        labels = np.ascontiguousarray(labels, np.int32)
+        c3 = np.full((K, 3), np.nan)
+        c2 = np.full((K, 2), np.nan)
+        counts = np.zeros(K, np.int64)
+        self._chk(lib().vcp_centroids(self._h, _ptr(xyz), _ptr(motor), _ptr(labels), C.c_int64(len(labels)),
+                                      C.c_int32(K), _ptr(c3), _ptr(c2), _ptr(counts)))
+        return c3, c2, counts
+
+    def merge_centroids(self, cxy, ids, thr):
+        cxy = _f64(cxy, 2)
+        ids = np.ascontiguousarray(ids, np.int32)
+        K = len(ids)
+        map_to = np.zeros(K, np.int32)
+        mc = C.c_int32(0)
+        self._chk(lib().vcp_merge_centroids(self._h, _ptr(cxy), _ptr(ids), C.c_int32(K), C.c_double(thr),
+                                            _ptr(map_to), C.byref(mc)))
+        return map_to, mc.value
+
+    def refresh_by_dictionary(self, xyz, motor, labels, K, map_by_id):
+        xyz = _f64(xyz, 3)
+        motor = _f64(motor, 2)
+        labels = np.array(labels, np.int32)
+        map_by_id = np.ascontiguousarray(map_by_id, np.int32)
+        c3 = np.zeros((K, 3))
+        c2 = np.zeros((K, 2))
+        counts = np.zeros(K, np.int64)
+        nk = C.c_int32(0)
+        self._chk(lib().vcp_refresh_by_dictionary(self._h, _ptr(xyz), _ptr(motor), _ptr(labels),
+                                                  C.c_int64(len(labels)), C.c_int32(K), _ptr(map_by_id),
+                                                  C.byref(nk), _ptr(c3), _ptr(c2), _ptr(counts)))
+        k = nk.value
+        return labels, k, c3[:k], c2[:k], counts[:k]
+
+    def match(self, centers, truths, M, max_dist):
+        centers = _f64(centers, 3)
+        truths = _f64(truths, 3)
+        M = _f64(M).reshape(16)
+        K, T = len(centers), len(truths)
+        mxyz = np.zeros((K, 3))
+        is_m = np.zeros(K, np.uint8)
+        nearest = np.zeros(K, np.int32)
+        nd = np.zeros(K)
+        cnt = C.c_int32(0)
+        self._chk(lib().vcp_match(self._h, _ptr(centers), C.c_int32(K), _ptr(truths), C.c_int32(T), _ptr(M),
+                                  C.c_double(max_dist), _ptr(mxyz), _ptr(is_m), _ptr(nearest), _ptr(nd),
+                                  C.byref(cnt)))
+        return dict(matched_xyz=mxyz, is_matched=is_m, nearest=nearest, nearest_dist=nd, count=cnt.value)

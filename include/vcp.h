@@ -111,12 +111,37 @@ int vcp_dbscan_dev(vcp_ctx* ctx, const double* d_coords, int64_t n, int dim, int
  * <= small_max points, one global DBImproved over all noise with cf preset).
  * motor [n*2]; labels [n] by original index (0 = noise or dropped); block_of [n] may be NULL
  * (-1 = in no block); merge_order [n] may be NULL: original indices in final clusForMerge
- * order, *m_out entries.  block_lo/block_hi: this context clusters only blocks
- * block_lo <= b < block_hi in step StartCode (multi-GPU sharding; 0,-1 = all). */
+ * order, *m_out entries.  kept = clusters surviving the demotion, del_sum = demoted clusters,
+ * cluster_amount = DBImproved.clusterAmount after the noise pass (FrmMain.cs:1521-1522). */
 int vcp_dbscan_blocks(vcp_ctx* ctx, const double* motor, int64_t n, double eps, int min_pts,
                       int pts_in_cell, int small_max, int32_t* labels, int32_t* block_of,
                       int64_t* merge_order, int64_t* m_out, int32_t* rows, int32_t* cols,
                       int32_t* kept, int32_t* del_sum, int32_t* cluster_amount, int64_t* dist_evals);
+
+/* The same pipeline in three stages, for sharding the per-block step over several GPUs (one
+ * process and one context per GPU, every rank holds the whole cloud; SURVEY.md 8e mode 1):
+ *   begin    partition (deterministic, identical on every rank); *m = points that fell in a block
+ *   share    contiguous block range of `rank`, balanced on point count, and the matching
+ *            [pos_lo, pos_hi) slice of the block-major label array
+ *   cluster  DBImproved per block for block_lo <= b < block_hi; writes the block-local cluster ids
+ *            (cf starts at 0 in every block, FrmMain.cs:2785) into d_local[pos_lo..pos_hi)
+ *   -- the caller all-gathers the slices of d_local (RCCL) and sums the per-rank evals --
+ *   finish   CompleteWork3 on the full d_local [m]; d_* outputs are device pointers
+ * The state lives in the context until the next begin. */
+int vcp_blocks_begin(vcp_ctx* ctx, const double* motor, int64_t n, double eps, int min_pts,
+                     int pts_in_cell, int small_max, int32_t* rows, int32_t* cols, int64_t* nblocks,
+                     int64_t* m);
+int vcp_blocks_begin_dev(vcp_ctx* ctx, const double* d_motor, int64_t n, double eps, int min_pts,
+                         int pts_in_cell, int small_max, int32_t* rows, int32_t* cols,
+                         int64_t* nblocks, int64_t* m);
+int vcp_blocks_share(vcp_ctx* ctx, int rank, int world, int32_t* block_lo, int32_t* block_hi,
+                     int64_t* pos_lo, int64_t* pos_hi);
+int vcp_blocks_cluster_dev(vcp_ctx* ctx, int32_t block_lo, int32_t block_hi, int32_t* d_local,
+                           int64_t* evals);
+int vcp_blocks_finish_dev(vcp_ctx* ctx, const int32_t* d_local, int64_t evals_blocks,
+                          int32_t* d_labels, int32_t* d_block_of, int64_t* d_merge_order,
+                          int64_t* m_out, int32_t* kept, int32_t* del_sum, int32_t* cluster_amount,
+                          int64_t* dist_evals);
 
 /* -- centroids ----------------------------------------------------------------------------
  * Replaces Tools.GetClusList (BC/Tools.cs:162-195; also getClusterCenter :118-155): per cluster

@@ -1,0 +1,94 @@
+"""GPU parity for the block-partitioned pipeline (getClusterFromMotor + StartCode + CompleteWork3,
+FrmMain.cs:1214-1291, :2782-2794, :1442-1520) through the C-ABI vs the CPU oracle: bit-exact labels,
+block assignment, clusForMerge order and counters -- including the reference's demotion quirks."""
+import numpy as np
+import pytest
+
+from vtkcloudpoint_amd import _native as N
+from vtkcloudpoint_amd import synth
+
+pytestmark = pytest.mark.gpu
+KEYS = ("labels", "block_of", "order", "rows", "cols", "kept", "del_sum", "cluster_amount", "evals")
+
+
+def _same(g, o, what):
+    for k in KEYS:
+        if isinstance(o[k], np.ndarray):
+            assert np.array_equal(g[k], o[k]), "%s: %s" % (what, k)
+        else:
+            assert g[k] == o[k], "%s: %s %r != %r" % (what, k, g[k], o[k])
+
+
+def test_random_small_incl_demotion_quirks(vcp_ctx, oracle):
+    rng = np.random.default_rng(1)
+    n_err = n_del = 0
+    for trial in range(300):
+        n = int(rng.integers(5, 400))
+        motor = (rng.integers(0, 40, size=(n, 2)).astype(np.float64) * 0.25 if trial % 2
+                 else rng.random((n, 2)) * 10)
+        eps = float(rng.choice([0.25, 0.5, 0.75]))
+        mp = int(rng.integers(1, 6))
+        pic = int(rng.integers(3, 60))
+        try:
+            o = oracle.block_pipeline(motor, eps, mp, pic, 3)
+        except oracle.OracleError as e:
+            n_err += 1
+            with pytest.raises(N.VcpError) as ge:
+                vcp_ctx.dbscan_blocks(motor, eps, mp, pic, 3)
+            assert ge.value.code == e.code, "trial %d error code" % trial
+            continue
+        g = vcp_ctx.dbscan_blocks(motor, eps, mp, pic, 3)
+        _same(g, o, "trial %d" % trial)
+        n_del += o["del_sum"] > 0
+    assert n_err > 0 and n_del > 0  # the quirk paths were really exercised
+
+
+def test_reference_defaults_200k_and_1m(vcp_ctx, oracle):
+    for n, seed in ((200_000, 9), (1_000_000, 2)):
+        d = synth.config_cloud(n, seed=seed)
+        # the reference UI defaults: eps 0.07, minPts 7, 200 points per block (Clustering.Designer.cs:86,96,158)
+        for eps, mp, pic in ((0.07, 7, 200), (d["eps_l1"], d["min_pts"], 500)):
+            o = oracle.block_pipeline(d["motor"], eps, mp, pic, 3)
+            g = vcp_ctx.dbscan_blocks(d["motor"], eps, mp, pic, 3)
+            _same(g, o, "n=%d eps=%g" % (n, eps))
+
+
+def test_staged_equals_one_shot(vcp_ctx, oracle):
+    import torch
+    d = synth.config_cloud(200_000, seed=9)
+    eps, mp, pic = 0.1, 10, 200
+    ref = vcp_ctx.dbscan_blocks(d["motor"], eps, mp, pic, 3)
+    info = vcp_ctx.blocks_begin(d["motor"], eps, mp, pic, 3)
+    assert info["rows"] == ref["rows"] and info["cols"] == ref["cols"] and info["m"] == len(ref["order"])
+    m, n = info["m"], len(d["motor"])
+    local = torch.zeros(m, dtype=torch.int32, device="cuda")
+    evals = 0
+    world = 3
+    covered = 0
+    for r in range(world):  # three "ranks" on one GPU: contiguous balanced block ranges
+        lo, hi, plo, phi = vcp_ctx.blocks_share(r, world)
+        assert plo == covered
+        covered = phi
+        evals += vcp_ctx.blocks_cluster_dev(lo, hi, local.data_ptr())
+    assert covered == m
+    labels = torch.zeros(n, dtype=torch.int32, device="cuda")
+    block_of = torch.zeros(n, dtype=torch.int32, device="cuda")
+    order = torch.zeros(m, dtype=torch.int64, device="cuda")
+    out = vcp_ctx.blocks_finish_dev(local.data_ptr(), evals, labels.data_ptr(), block_of.data_ptr(), order.data_ptr())
+    assert np.array_equal(labels.cpu().numpy(), ref["labels"])
+    assert np.array_equal(block_of.cpu().numpy(), ref["block_of"])
+    assert np.array_equal(order.cpu().numpy(), ref["order"])
+    assert out["kept"] == ref["kept"] and out["cluster_amount"] == ref["cluster_amount"]
+    assert out["evals"] == ref["evals"]
+
+
+def test_errors(vcp_ctx):
+    with pytest.raises(N.VcpError) as e:
+        vcp_ctx.dbscan_blocks(np.zeros((0, 2)), 0.1, 3, 10)
+    assert e.value.code == -2  # Min() of an empty list
+    with pytest.raises(N.VcpError) as e:
+        vcp_ctx.dbscan_blocks(np.random.rand(10, 2), 0.1, 3, 0)
+    assert e.value.code == -2  # Take(0).Max()
+    with pytest.raises(N.VcpError) as e:
+        vcp_ctx.dbscan_blocks(np.ones((10, 2)), 0.1, 3, 5)
+    assert e.value.code == -3  # zero-extent first block

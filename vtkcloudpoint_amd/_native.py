@@ -21,7 +21,8 @@ STATUS = {
 SYMBOLS = [
     "vcp_create", "vcp_destroy", "vcp_last_error", "vcp_version", "vcp_set_stream", "vcp_dev_alloc",
     "vcp_dev_free", "vcp_h2d", "vcp_d2h", "vcp_timing_enable", "vcp_timing_count", "vcp_timing_get",
-    "vcp_dbscan", "vcp_dbscan_dev", "vcp_dbscan_blocks", "vcp_centroids", "vcp_centroids_dev",
+    "vcp_dbscan", "vcp_dbscan_dev", "vcp_dbscan_blocks", "vcp_blocks_begin", "vcp_blocks_begin_dev",
+    "vcp_blocks_share", "vcp_blocks_cluster_dev", "vcp_blocks_finish_dev", "vcp_centroids", "vcp_centroids_dev",
     "vcp_merge_centroids", "vcp_refresh_by_dictionary", "vcp_icp", "vcp_icp_dev", "vcp_icp_sums",
     "vcp_match",
 ]
@@ -43,6 +44,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("libvcp.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "or `make -C vtkcloudpoint_amd/csrc`")
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 with the same soname as
+        # /opt/rocm's.  Whichever loads first serves both; letting torch load first keeps torch.cuda and
+        # torch.distributed (RCCL) working next to libvcp in the same process.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _lib.vcp_last_error.restype = C.c_char_p
         _lib.vcp_last_error.argtypes = [C.c_void_p]
@@ -227,3 +235,58 @@ class Context:
                                   C.c_double(max_dist), _ptr(mxyz), _ptr(is_m), _ptr(nearest), _ptr(nd),
                                   C.byref(cnt)))
         return dict(matched_xyz=mxyz, is_matched=is_m, nearest=nearest, nearest_dist=nd, count=cnt.value)
+
+    # -- block-partitioned pipeline ------------------------------------------------------------------
+    def dbscan_blocks(self, motor, eps, min_pts, pts_in_cell, small_max=3):
+        """MainForm.getClusterFromMotor + StartCode + CompleteWork3 in one call (host buffers)."""
+        motor = _f64(motor, 2)
+        n = len(motor)
+        labels = np.zeros(n, np.int32)
+        block_of = np.zeros(n, np.int32)
+        order = np.zeros(max(n, 1), np.int64)
+        m = C.c_int64(0)
+        rows, cols, kept, dels, ca = (C.c_int32(0) for _ in range(5))
+        ev = C.c_int64(0)
+        self._chk(lib().vcp_dbscan_blocks(self._h, _ptr(motor), C.c_int64(n), C.c_double(eps), int(min_pts),
+                                          int(pts_in_cell), int(small_max), _ptr(labels), _ptr(block_of),
+                                          _ptr(order), C.byref(m), C.byref(rows), C.byref(cols), C.byref(kept),
+                                          C.byref(dels), C.byref(ca), C.byref(ev)))
+        return dict(labels=labels, block_of=block_of, order=order[: m.value].copy(), rows=rows.value,
+                    cols=cols.value, kept=kept.value, del_sum=dels.value, cluster_amount=ca.value,
+                    evals=ev.value)
+
+    def blocks_begin(self, motor, eps, min_pts, pts_in_cell, small_max=3, device_ptr=None, n=None):
+        rows, cols = C.c_int32(0), C.c_int32(0)
+        nb, m = C.c_int64(0), C.c_int64(0)
+        if device_ptr is None:
+            motor = _f64(motor, 2)
+            self._chk(lib().vcp_blocks_begin(self._h, _ptr(motor), C.c_int64(len(motor)), C.c_double(eps),
+                                             int(min_pts), int(pts_in_cell), int(small_max), C.byref(rows),
+                                             C.byref(cols), C.byref(nb), C.byref(m)))
+        else:
+            self._chk(lib().vcp_blocks_begin_dev(self._h, _ptr(device_ptr), C.c_int64(n), C.c_double(eps),
+                                                 int(min_pts), int(pts_in_cell), int(small_max), C.byref(rows),
+                                                 C.byref(cols), C.byref(nb), C.byref(m)))
+        return dict(rows=rows.value, cols=cols.value, nblocks=nb.value, m=m.value)
+
+    def blocks_share(self, rank, world):
+        lo, hi = C.c_int32(0), C.c_int32(0)
+        plo, phi = C.c_int64(0), C.c_int64(0)
+        self._chk(lib().vcp_blocks_share(self._h, int(rank), int(world), C.byref(lo), C.byref(hi), C.byref(plo),
+                                         C.byref(phi)))
+        return lo.value, hi.value, plo.value, phi.value
+
+    def blocks_cluster_dev(self, block_lo, block_hi, d_local):
+        ev = C.c_int64(0)
+        self._chk(lib().vcp_blocks_cluster_dev(self._h, C.c_int32(block_lo), C.c_int32(block_hi), _ptr(d_local),
+                                               C.byref(ev)))
+        return ev.value
+
+    def blocks_finish_dev(self, d_local, evals_blocks, d_labels, d_block_of=None, d_merge_order=None):
+        m = C.c_int64(0)
+        kept, dels, ca = (C.c_int32(0) for _ in range(3))
+        ev = C.c_int64(0)
+        self._chk(lib().vcp_blocks_finish_dev(self._h, _ptr(d_local), C.c_int64(evals_blocks), _ptr(d_labels),
+                                              _ptr(d_block_of), _ptr(d_merge_order), C.byref(m), C.byref(kept),
+                                              C.byref(dels), C.byref(ca), C.byref(ev)))
+        return dict(m=m.value, kept=kept.value, del_sum=dels.value, cluster_amount=ca.value, evals=ev.value)

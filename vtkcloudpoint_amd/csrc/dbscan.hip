@@ -1,40 +1,41 @@
 // dbscan.hip -- DBImproved.dbscan on MI355X (gfx950).
 //
 // Semantics: BaseClass/DBImproved.cs:14-114 in the order-free form of SURVEY.md 8a row A3 (see
-// include/vcp.h).  All distance arithmetic is binary64 with FMA contraction OFF, so the
-// `d <= eps` predicate is bit-identical to the C#'s (SSE2) evaluation; the grid only proposes
-// candidates and is conservative by construction (cell edge = eps * (1 + 2^-20)).
+// include/vcp.h).  All distance arithmetic is binary64 with FMA contraction OFF, so the `d <= eps`
+// predicate is bit-identical to the C#'s (SSE2) evaluation; the grid only proposes candidates and is
+// conservative by construction (cell edge = eps * (1 + 2^-20), candidates re-tested exactly).
 //
-// Data layout in HBM (n points, sorted position p, original index i):
+// Data layout in HBM (n points, original index i, sorted position p, GD = dimension of the metric):
 //   cellcnt [ncells+1] u32   histogram, then exclusive scan = first sorted position of each cell
 //   cellof  [n] u32, rank [n] u32   cell id / arrival rank inside the cell, by original index
-//   sorted  [n*DIM] f64      coordinates in cell order (x-fastest linear cell id)
-//   sidx    [n] u32          original index of sorted position p
-//   flags   [n] u8           bit0 core, bit1 classed on entry, bit2 expanding
-//   parent  [n] u32          union-find over sorted positions (pointers only decrease)
-//   minord  [n] u32          per root: smallest original index in the component
-//   seedflag[n] u32          1 at the original index of each component's seed, then its scan
-//   rootcl  [n] i32          per root: final cluster id;  clseed [K] u32: seed index per cluster
+//   pos     [n] u32          sorted position of original index i (NONE = excluded from this call)
+//   sorted  [nin*GD] f64     coordinates in cell order (x-fastest linear cell id)
+//   sord    [nin] u32        "list position" of the point (original index, or the caller's ord)
+//   sgroup  [nin] i32        group (block) of the point, grouped calls only
+//   flags   [nin] u8         bit0 core, bit1 classed on entry, bit2 expanding
+//   parent  [nin] u32        union-find over sorted positions (pointers only decrease)
+//   minord  [nin] u32        per root: smallest list position in the component (= the seed)
+//   seedflag[n+1] u32        1 at the list position of each seed, then its exclusive scan
+//   rootk   [nin] u32        per root: rank of its seed among all seeds; clseed [K]: seed per rank
+//   labk    [nin] u32        per point: 1 + seed rank of its final cluster, 0 = none
+// Passes: bounds -> cell_hist -> scan -> scatter -> core -> union -> flatten/number -> border -> output.
 #include <cmath>
 #include <cstring>
 #include <limits>
 
-#include "vcp_ctx.hpp"
+#include "dbscan_engine.hpp"
 
 namespace {
 
 constexpr int TPB = 256;
 constexpr uint8_t F_CORE = 1, F_CLASSED = 2, F_EXPAND = 4;
+constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 struct GridP {
   double mn[3];
   double inv_h;
   int D[3];
-  int gdim;
-};
-
-struct PredP {
-  double thr;  // L1: eps; L2: largest s with sqrt(s) <= eps
+  uint32_t ncells;
 };
 
 template <int METRIC>
@@ -58,9 +59,9 @@ __device__ __forceinline__ int cell_coord(double x, double mn, double inv_h, int
   return 0;  // below the minimum or NaN
 }
 
-template <int DIM>
+template <int GD>
 __device__ __forceinline__ void load_pt(const double* __restrict__ c, int64_t i, double* q) {
-  if (DIM == 2) {
+  if (GD == 2) {
     double2 v = *reinterpret_cast<const double2*>(c + 2 * i);
     q[0] = v.x;
     q[1] = v.y;
@@ -96,25 +97,7 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
-// partial[b*6 + a] = min of axis a, partial[b*6 + 3 + a] = max, over finite values only
-template <int DIM>
-__global__ __launch_bounds__(TPB) void k_bounds(const double* __restrict__ c, int64_t n, int stride,
-                                               double* __restrict__ partial) {
-  double mn[3], mx[3];
-  for (int a = 0; a < 3; a++) {
-    mn[a] = INFINITY;
-    mx[a] = -INFINITY;
-  }
-  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
-#pragma unroll
-    for (int a = 0; a < DIM; a++) {
-      double v = c[i * stride + a];
-      if (isfinite(v)) {
-        mn[a] = fmin(mn[a], v);
-        mx[a] = fmax(mx[a], v);
-      }
-    }
-  }
+__device__ __forceinline__ void block_minmax(double* mn, double* mx, double* __restrict__ out6) {
   __shared__ double sm[TPB / 64][6];
   int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -130,104 +113,158 @@ __global__ __launch_bounds__(TPB) void k_bounds(const double* __restrict__ c, in
     double v = sm[0][threadIdx.x];
     for (int k = 1; k < TPB / 64; k++)
       v = threadIdx.x < 3 ? fmin(v, sm[k][threadIdx.x]) : fmax(v, sm[k][threadIdx.x]);
-    partial[blockIdx.x * 6 + threadIdx.x] = v;
+    out6[threadIdx.x] = v;
   }
 }
 
-__global__ void k_bounds_final(const double* __restrict__ partial, int nb, double* __restrict__ out) {
-  int a = threadIdx.x;
-  if (a >= 6) return;
-  double v = partial[a];
-  for (int b = 1; b < nb; b++) v = a < 3 ? fmin(v, partial[b * 6 + a]) : fmax(v, partial[b * 6 + a]);
-  out[a] = v;
+// partial[b*6 + a] = min of axis a, partial[b*6 + 3 + a] = max, over finite values only
+template <int GD, bool GROUPED>
+__global__ __launch_bounds__(TPB) void k_bounds(const double* __restrict__ c, int64_t n, int stride,
+                                               const int32_t* __restrict__ group, int glo, int ghi,
+                                               double* __restrict__ partial) {
+  double mn[3], mx[3];
+  for (int a = 0; a < 3; a++) {
+    mn[a] = INFINITY;
+    mx[a] = -INFINITY;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+    if (GROUPED) {
+      int g = group[i];
+      if (g < glo || g >= ghi) continue;
+    }
+#pragma unroll
+    for (int a = 0; a < GD; a++) {
+      double v = c[i * stride + a];
+      if (isfinite(v)) {
+        mn[a] = fmin(mn[a], v);
+        mx[a] = fmax(mx[a], v);
+      }
+    }
+  }
+  block_minmax(mn, mx, partial + (size_t)blockIdx.x * 6);
+}
+
+__global__ __launch_bounds__(TPB) void k_bounds_final(const double* __restrict__ partial, int nb,
+                                                     double* __restrict__ out) {
+  double mn[3], mx[3];
+  for (int a = 0; a < 3; a++) {
+    mn[a] = INFINITY;
+    mx[a] = -INFINITY;
+  }
+  for (int b = threadIdx.x; b < nb; b += TPB)
+    for (int a = 0; a < 3; a++) {
+      mn[a] = fmin(mn[a], partial[b * 6 + a]);
+      mx[a] = fmax(mx[a], partial[b * 6 + 3 + a]);
+    }
+  block_minmax(mn, mx, out);
 }
 
 // ---- grid build -------------------------------------------------------------------------------
-template <int DIM>
+template <int GD>
 __device__ __forceinline__ uint32_t cell_of(const double* q, const GridP& g, int* cc) {
   cc[0] = cell_coord(q[0], g.mn[0], g.inv_h, g.D[0]);
   cc[1] = cell_coord(q[1], g.mn[1], g.inv_h, g.D[1]);
   uint32_t id = (uint32_t)cc[1] * (uint32_t)g.D[0] + (uint32_t)cc[0];
-  if (DIM == 3) {
+  if (GD == 3) {
     cc[2] = cell_coord(q[2], g.mn[2], g.inv_h, g.D[2]);
     id += (uint32_t)cc[2] * (uint32_t)g.D[0] * (uint32_t)g.D[1];
   }
   return id;
 }
 
-template <int DIM>
+template <int GD, bool GROUPED>
 __global__ __launch_bounds__(TPB) void k_cell_hist(const double* __restrict__ c, int64_t n, int stride, GridP g,
+                                                  const int32_t* __restrict__ group, int glo, int ghi,
                                                   uint32_t* __restrict__ cellcnt, uint32_t* __restrict__ cellof,
                                                   uint32_t* __restrict__ rank) {
   int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
   if (i >= n) return;
+  if (GROUPED) {
+    int gg = group[i];
+    if (gg < glo || gg >= ghi) {
+      cellof[i] = NONE;
+      return;
+    }
+  }
   double q[3];
   int cc[3];
-  load_in<DIM>(c, i, stride, q);
-  uint32_t id = cell_of<DIM>(q, g, cc);
+  load_in<GD>(c, i, stride, q);
+  uint32_t id = cell_of<GD>(q, g, cc);
   cellof[i] = id;
   rank[i] = atomicAdd(&cellcnt[id], 1u);
 }
 
-template <int DIM>
+template <int GD, bool GROUPED>
 __global__ __launch_bounds__(TPB) void k_scatter(const double* __restrict__ c, int64_t n, int stride,
                                                 const uint32_t* __restrict__ cellstart,
                                                 const uint32_t* __restrict__ cellof,
                                                 const uint32_t* __restrict__ rank,
                                                 const uint8_t* __restrict__ in_classed,
-                                                double* __restrict__ sorted, uint32_t* __restrict__ sidx,
+                                                const int32_t* __restrict__ group, const uint32_t* __restrict__ ord,
+                                                uint32_t* __restrict__ pos, double* __restrict__ sorted,
+                                                uint32_t* __restrict__ sord, int32_t* __restrict__ sgroup,
                                                 uint8_t* __restrict__ flags) {
   int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
   if (i >= n) return;
-  uint32_t p = cellstart[cellof[i]] + rank[i];
+  uint32_t cid = cellof[i];
+  if (GROUPED && cid == NONE) {
+    pos[i] = NONE;
+    return;
+  }
+  uint32_t p = cellstart[cid] + rank[i];
+  pos[i] = p;
   double q[3];
-  load_in<DIM>(c, i, stride, q);
-  if (DIM == 2) {
+  load_in<GD>(c, i, stride, q);
+  if (GD == 2) {
     *reinterpret_cast<double2*>(sorted + 2 * (int64_t)p) = make_double2(q[0], q[1]);
   } else {
     sorted[3 * (int64_t)p] = q[0];
     sorted[3 * (int64_t)p + 1] = q[1];
     sorted[3 * (int64_t)p + 2] = q[2];
   }
-  sidx[p] = (uint32_t)i;
-  flags[p] = (in_classed && in_classed[i]) ? F_CLASSED : 0;
+  sord[p] = ord ? ord[i] : (uint32_t)i;
+  if (GROUPED) sgroup[p] = group[i];
+  if (in_classed) flags[p] = in_classed[i] ? F_CLASSED : 0;  // otherwise flags were zero-filled
 }
 
-// iterate the candidate rows of sorted position p: f(j) for every j in the 3 (9) x-rows of the
-// cell neighbourhood; f returns false to stop early.
-template <int DIM, class F>
+// iterate the candidate rows of a cell neighbourhood: f(s, e) for the position range of each of the
+// 3 (9) x-rows, in increasing position order; f returns false to stop early.
+template <int GD, class F>
 __device__ __forceinline__ void for_rows(const int* cc, const GridP& g, const uint32_t* __restrict__ cellstart, F&& f) {
   int x0 = max(cc[0] - 1, 0), x1 = min(cc[0] + 1, g.D[0] - 1);
   int y0 = max(cc[1] - 1, 0), y1 = min(cc[1] + 1, g.D[1] - 1);
   int z0 = 0, z1 = 0;
-  if (DIM == 3) {
+  if (GD == 3) {
     z0 = max(cc[2] - 1, 0);
     z1 = min(cc[2] + 1, g.D[2] - 1);
   }
   for (int z = z0; z <= z1; z++)
     for (int y = y0; y <= y1; y++) {
-      uint32_t base = ((DIM == 3 ? (uint32_t)z * (uint32_t)g.D[1] : 0u) + (uint32_t)y) * (uint32_t)g.D[0];
+      uint32_t base = ((GD == 3 ? (uint32_t)z * (uint32_t)g.D[1] : 0u) + (uint32_t)y) * (uint32_t)g.D[0];
       uint32_t s = cellstart[base + x0], e = cellstart[base + x1 + 1];
       if (!f(s, e)) return;
     }
 }
 
 // ---- core flags (region query with early exit at min_pts) ---------------------------------------
-template <int DIM, int METRIC>
-__global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted, int64_t n, GridP g, double thr,
-                                             int min_pts, const uint32_t* __restrict__ cellstart,
-                                             uint8_t* __restrict__ flags) {
+template <int GD, int METRIC, bool GROUPED>
+__global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted, GridP g, double thr, int min_pts,
+                                             const uint32_t* __restrict__ cellstart,
+                                             const int32_t* __restrict__ sgroup, uint8_t* __restrict__ flags) {
+  const uint32_t nin = cellstart[g.ncells];
   int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
-  if (p >= n) return;
+  if (p >= nin) return;
   double q[3];
   int cc[3];
-  load_pt<DIM>(sorted, p, q);
-  cell_of<DIM>(q, g, cc);
+  load_pt<GD>(sorted, p, q);
+  cell_of<GD>(q, g, cc);
+  const int32_t myg = GROUPED ? sgroup[p] : 0;
   int cnt = 0;
-  for_rows<DIM>(cc, g, cellstart, [&](uint32_t s, uint32_t e) {
+  for_rows<GD>(cc, g, cellstart, [&](uint32_t s, uint32_t e) {
     for (uint32_t j = s; j < e; j++) {
+      if (GROUPED && sgroup[j] != myg) continue;
       double r[3];
-      load_pt<DIM>(sorted, j, r);
+      load_pt<GD>(sorted, j, r);
       if (within<METRIC>(q, r, thr)) {
         if (++cnt >= min_pts) return false;
       }
@@ -243,161 +280,244 @@ __global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted,
 }
 
 // ---- union-find over expanding points -------------------------------------------------------------
+// Pointers always go from a larger to a smaller position, so the forest stays acyclic under any
+// interleaving.  Loads may be stale (another XCD's L2): a stale value is an OLDER ancestor link, still
+// valid; every structural change goes through a device-scope CAS, which is the arbiter.
 __device__ __forceinline__ uint32_t ld_parent(const uint32_t* parent, uint32_t x) {
   return __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ uint32_t uf_find(uint32_t* parent, uint32_t x) {
+__device__ __forceinline__ uint32_t uf_root(const uint32_t* parent, uint32_t x) {
   uint32_t p = ld_parent(parent, x);
   while (p != x) {
-    uint32_t gp = ld_parent(parent, p);
-    if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // path halving
     x = p;
-    p = gp;
+    p = ld_parent(parent, x);
   }
   return x;
 }
 
-// pointers always go from a larger to a smaller position, so the forest stays acyclic under any
-// interleaving; a stale read only ever shows an OLDER ancestor link, and the CAS is the arbiter.
-__device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t b) {
-  uint32_t ra = uf_find(parent, a), rb = uf_find(parent, b);
+// hook the trees of roots ra, rb (either may turn out not to be a root); returns the surviving root
+__device__ __forceinline__ uint32_t uf_link(uint32_t* parent, uint32_t ra, uint32_t rb) {
   while (ra != rb) {
     if (ra < rb) {
       uint32_t t = ra;
       ra = rb;
       rb = t;
     }
-    uint32_t old = atomicCAS(&parent[ra], ra, rb);
-    if (old == ra) return;
-    ra = uf_find(parent, old);
+    uint32_t old = atomicCAS(&parent[ra], ra, rb);  // ra > rb
+    if (old == ra) return rb;
+    ra = uf_root(parent, old);
+    rb = uf_root(parent, rb);
   }
+  return ra;
 }
 
 __global__ __launch_bounds__(TPB) void k_init_parent(uint32_t* __restrict__ parent, uint32_t* __restrict__ minord,
-                                                    int64_t n) {
+                                                    const uint32_t* __restrict__ cellstart, uint32_t ncells) {
+  const uint32_t nin = cellstart[ncells];
   int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
-  if (p >= n) return;
+  if (p >= nin) return;
   parent[p] = (uint32_t)p;
-  minord[p] = 0xFFFFFFFFu;
+  minord[p] = NONE;
 }
 
-template <int DIM, int METRIC>
-__global__ __launch_bounds__(TPB) void k_union(const double* __restrict__ sorted, int64_t n, GridP g, double thr,
+template <int GD, int METRIC, bool GROUPED>
+__global__ __launch_bounds__(TPB) void k_union(const double* __restrict__ sorted, GridP g, double thr,
                                               const uint32_t* __restrict__ cellstart,
-                                              const uint8_t* __restrict__ flags, uint32_t* __restrict__ parent) {
+                                              const int32_t* __restrict__ sgroup, const uint8_t* __restrict__ flags,
+                                              uint32_t* __restrict__ parent) {
+  const uint32_t nin = cellstart[g.ncells];
   int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
-  if (p >= n) return;
+  if (p >= nin) return;
   if (!(flags[p] & F_EXPAND)) return;
   double q[3];
   int cc[3];
-  load_pt<DIM>(sorted, p, q);
-  cell_of<DIM>(q, g, cc);
+  load_pt<GD>(sorted, p, q);
+  cell_of<GD>(q, g, cc);
+  const int32_t myg = GROUPED ? sgroup[p] : 0;
   const uint32_t me = (uint32_t)p;
-  for_rows<DIM>(cc, g, cellstart, [&](uint32_t s, uint32_t e) {
-    if (s >= me) return false;  // rows are visited in increasing position: nothing below me is left
+  uint32_t rp = me;  // cached root of my tree
+  for_rows<GD>(cc, g, cellstart, [&](uint32_t s, uint32_t e) {
+    if (s >= me) return false;  // rows come in increasing position: nothing below me is left
     if (e > me) e = me;         // every undirected edge is handled by its larger endpoint
     for (uint32_t j = s; j < e; j++) {
       if (!(flags[j] & F_EXPAND)) continue;
+      if (GROUPED && sgroup[j] != myg) continue;
       double r[3];
-      load_pt<DIM>(sorted, j, r);
-      if (within<METRIC>(q, r, thr)) uf_union(parent, me, j);
+      load_pt<GD>(sorted, j, r);
+      if (!within<METRIC>(q, r, thr)) continue;
+      uint32_t rj = uf_root(parent, j);
+      rp = uf_root(parent, rp);
+      if (rj != rp) rp = uf_link(parent, rp, rj);
     }
     return true;
   });
+  // one compression store per point (rp is an ancestor of me, so the link stays valid)
+  if (rp != me) __hip_atomic_store(&parent[me], rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// flatten + smallest original index per component
+// flatten + smallest list position per component; lanes of a wave that share a root (the common
+// case inside a blob: the wave covers neighbouring cells) combine before one atomicMin
 __global__ __launch_bounds__(TPB) void k_flatten(uint32_t* __restrict__ parent, const uint8_t* __restrict__ flags,
-                                                const uint32_t* __restrict__ sidx, uint32_t* __restrict__ minord,
-                                                int64_t n) {
+                                                const uint32_t* __restrict__ sord, uint32_t* __restrict__ minord,
+                                                const uint32_t* __restrict__ cellstart, uint32_t ncells) {
+  const uint32_t nin = cellstart[ncells];
   int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
-  if (p >= n) return;
-  if (!(flags[p] & F_EXPAND)) return;
-  uint32_t r = (uint32_t)p;
-  uint32_t x = parent[r];
-  while (x != r) {
-    r = x;
-    x = parent[r];
+  uint32_t r = NONE, v = NONE;
+  if (p < nin && (flags[p] & F_EXPAND)) {
+    r = (uint32_t)p;
+    uint32_t x = parent[r];
+    while (x != r) {
+      r = x;
+      x = parent[r];
+    }
+    parent[p] = r;  // roots keep pointing at themselves, so concurrent flattening is safe
+    v = sord[p];
   }
-  parent[p] = r;  // roots keep pointing at themselves, so concurrent flattening is safe
-  atomicMin(&minord[r], sidx[p]);
+  unsigned long long todo = __ballot(r != NONE);
+  const int lane = threadIdx.x & 63;
+  while (todo) {
+    int leader = __ffsll((long long)todo) - 1;
+    uint32_t lr = __shfl(r, leader, 64);
+    bool mine = (r == lr);
+    uint32_t m = mine ? v : NONE;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, d, 64));
+    if (lane == leader) atomicMin(&minord[lr], m);
+    todo &= ~__ballot(mine);
+  }
 }
 
 __global__ __launch_bounds__(TPB) void k_seedflag(const uint32_t* __restrict__ parent, const uint8_t* __restrict__ flags,
                                                  const uint32_t* __restrict__ minord, uint32_t* __restrict__ seedflag,
-                                                 int64_t n) {
+                                                 const uint32_t* __restrict__ cellstart, uint32_t ncells) {
+  const uint32_t nin = cellstart[ncells];
   int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
-  if (p >= n) return;
+  if (p >= nin) return;
   if ((flags[p] & F_EXPAND) && parent[p] == (uint32_t)p) seedflag[minord[p]] = 1u;
 }
 
-__global__ __launch_bounds__(TPB) void k_rootid(const uint32_t* __restrict__ parent, const uint8_t* __restrict__ flags,
-                                               const uint32_t* __restrict__ minord, const uint32_t* __restrict__ seedrank,
-                                               int32_t cf_in, int32_t* __restrict__ rootcl, uint32_t* __restrict__ clseed,
-                                               int64_t n) {
+__global__ __launch_bounds__(TPB) void k_rootk(const uint32_t* __restrict__ parent, const uint8_t* __restrict__ flags,
+                                              const uint32_t* __restrict__ minord, const uint32_t* __restrict__ seedrank,
+                                              uint32_t* __restrict__ rootk, uint32_t* __restrict__ clseed,
+                                              const uint32_t* __restrict__ cellstart, uint32_t ncells) {
+  const uint32_t nin = cellstart[ncells];
   int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
-  if (p >= n) return;
+  if (p >= nin) return;
   if ((flags[p] & F_EXPAND) && parent[p] == (uint32_t)p) {
     uint32_t k = seedrank[minord[p]];
-    rootcl[p] = cf_in + 1 + (int32_t)k;
+    rootk[p] = k;
     clseed[k] = minord[p];
   }
 }
 
-// ---- final labels, border rule, outputs in caller order, op counter ----------------------------
-// counters[0] = points not classed on entry, counters[1] = border points queried twice
-template <int DIM, int METRIC>
-__global__ __launch_bounds__(TPB) void k_label(const double* __restrict__ sorted, int64_t n, GridP g, double thr,
-                                              const uint32_t* __restrict__ cellstart, const uint8_t* __restrict__ flags,
-                                              const uint32_t* __restrict__ parent, const uint32_t* __restrict__ sidx,
-                                              const int32_t* __restrict__ rootcl, const uint32_t* __restrict__ clseed,
-                                              int32_t cf_in, int fresh, int32_t* __restrict__ labels,
-                                              uint8_t* __restrict__ is_core, uint8_t* __restrict__ is_classed,
-                                              unsigned long long* __restrict__ counters) {
+// ---- border rule: labk[p] = 1 + seed rank of the final cluster ------------------------------------
+// twice[...] counts border points the C# main loop had already queried before their first cluster's
+// seed came up (BaseClass/DBImproved.cs:93-104 then :63-67)
+template <int GD, int METRIC, bool GROUPED>
+__global__ __launch_bounds__(TPB) void k_border(const double* __restrict__ sorted, GridP g, double thr,
+                                               const uint32_t* __restrict__ cellstart,
+                                               const int32_t* __restrict__ sgroup, const uint8_t* __restrict__ flags,
+                                               const uint32_t* __restrict__ parent, const uint32_t* __restrict__ sord,
+                                               const uint32_t* __restrict__ rootk, const uint32_t* __restrict__ clseed,
+                                               uint32_t* __restrict__ labk, unsigned long long* __restrict__ counters,
+                                               uint32_t* __restrict__ group_twice) {
+  const uint32_t nin = cellstart[g.ncells];
   int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
-  unsigned unclassed = 0, twice = 0;
-  if (p < n) {
-    uint8_t fl = flags[p];
-    uint32_t orig = sidx[p];
-    int32_t lab = 0;
+  unsigned twice = 0;
+  if (p < nin) {
+    const uint8_t fl = flags[p];
+    uint32_t out = 0;
     if (fl & F_EXPAND) {
-      lab = rootcl[parent[p]];
+      out = rootk[parent[p]] + 1u;
     } else {
       double q[3];
       int cc[3];
-      load_pt<DIM>(sorted, p, q);
-      cell_of<DIM>(q, g, cc);
-      int32_t mx = 0, mnid = 0x7FFFFFFF;
-      for_rows<DIM>(cc, g, cellstart, [&](uint32_t s, uint32_t e) {
+      load_pt<GD>(sorted, p, q);
+      cell_of<GD>(q, g, cc);
+      const int32_t myg = GROUPED ? sgroup[p] : 0;
+      uint32_t mx = 0, mnk = NONE;
+      for_rows<GD>(cc, g, cellstart, [&](uint32_t s, uint32_t e) {
         for (uint32_t j = s; j < e; j++) {
           if (!(flags[j] & F_EXPAND)) continue;
+          if (GROUPED && sgroup[j] != myg) continue;
           double r[3];
-          load_pt<DIM>(sorted, j, r);
+          load_pt<GD>(sorted, j, r);
           if (within<METRIC>(q, r, thr)) {
-            int32_t id = rootcl[parent[j]];
-            mx = max(mx, id);
-            mnid = min(mnid, id);
+            uint32_t k = rootk[parent[j]];
+            mx = max(mx, k + 1u);
+            mnk = min(mnk, k);
           }
         }
         return true;
       });
-      lab = mx;
-      // reached first by cluster mnid; the C# main loop had already queried it once iff it sits
-      // before that cluster's seed (BaseClass/DBImproved.cs:93-104 then :63-67)
-      if (mx != 0 && !(fl & F_CLASSED) && orig < clseed[mnid - cf_in - 1]) twice = 1;
+      out = mx;
+      if (mx != 0 && !(fl & F_CLASSED) && sord[p] < clseed[mnk]) {
+        twice = 1;
+        if (GROUPED) atomicAdd(&group_twice[myg], 1u);
+      }
     }
-    if (!(fl & F_CLASSED)) unclassed = 1;
-    if (lab != 0 || fresh) labels[orig] = lab;
-    if (is_core) is_core[orig] = ((fl & F_CORE) && !(fl & F_CLASSED)) ? 1 : 0;
-    if (is_classed) is_classed[orig] = ((fl & F_CLASSED) || lab != 0) ? 1 : 0;
+    labk[p] = out;
   }
-  // wave-level reduction, one atomic per wave
-  unsigned long long m1 = __ballot(unclassed), m2 = __ballot(twice);
-  if ((threadIdx.x & 63) == 0) {
-    if (m1) atomicAdd(&counters[0], (unsigned long long)__popcll(m1));
-    if (m2) atomicAdd(&counters[1], (unsigned long long)__popcll(m2));
+  if (!GROUPED) {
+    unsigned long long m2 = __ballot(twice);
+    if ((threadIdx.x & 63) == 0 && m2) atomicAdd(&counters[1], (unsigned long long)__popcll(m2));
   }
+}
+
+// ---- outputs in caller order (coalesced writes, gather from the sorted arrays) ------------------------
+template <bool GROUPED>
+__global__ __launch_bounds__(TPB) void k_output(int64_t n, const uint32_t* __restrict__ pos,
+                                               const uint8_t* __restrict__ flags, const uint32_t* __restrict__ labk,
+                                               const uint8_t* __restrict__ in_classed, const int32_t* __restrict__ group,
+                                               const uint32_t* __restrict__ groupstart,
+                                               const uint32_t* __restrict__ seedscan, int32_t cf_in,
+                                               int32_t* __restrict__ labels, uint8_t* __restrict__ is_core,
+                                               uint8_t* __restrict__ is_classed,
+                                               unsigned long long* __restrict__ counters) {
+  int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  unsigned unclassed = 0;
+  if (i < n) {
+    const uint32_t p = pos[i];
+    if (p == NONE) {  // excluded from this call
+      if (!in_classed) labels[i] = 0;
+      if (is_core) is_core[i] = 0;
+      if (is_classed) is_classed[i] = in_classed ? in_classed[i] : 0;
+    } else {
+      const uint8_t fl = flags[p];
+      const uint32_t k1 = labk[p];
+      int32_t lab = 0;
+      if (k1) {
+        uint32_t base = GROUPED ? seedscan[groupstart[group[i]]] : 0u;
+        lab = cf_in + (int32_t)(k1 - base);
+      }
+      if (lab != 0 || !in_classed) labels[i] = lab;
+      if (is_core) is_core[i] = ((fl & F_CORE) && !(fl & F_CLASSED)) ? 1 : 0;
+      if (is_classed) is_classed[i] = ((fl & F_CLASSED) || lab != 0) ? 1 : 0;
+      if (!(fl & F_CLASSED)) unclassed = 1;
+    }
+  }
+  unsigned long long m1 = __ballot(unclassed);
+  if ((threadIdx.x & 63) == 0 && m1) atomicAdd(&counters[0], (unsigned long long)__popcll(m1));
+}
+
+// per-group statistics: clusters per group and the op counter of the per-block DBImproved instances
+__global__ __launch_bounds__(TPB) void k_group_stats(int32_t G, int glo, int ghi, const uint32_t* __restrict__ groupstart,
+                                                    const uint32_t* __restrict__ seedscan,
+                                                    const uint32_t* __restrict__ group_twice,
+                                                    uint32_t* __restrict__ group_nclus,
+                                                    unsigned long long* __restrict__ evals) {
+  int g = blockIdx.x * TPB + threadIdx.x;
+  if (g >= G) return;
+  if (g < glo || g >= ghi) {
+    if (group_nclus) group_nclus[g] = 0;
+    return;
+  }
+  unsigned long long ng = groupstart[g + 1] - groupstart[g];
+  unsigned long long kg = seedscan[groupstart[g + 1]] - seedscan[groupstart[g]];
+  if (group_nclus) group_nclus[g] = (uint32_t)kg;
+  unsigned long long ev = ng * (ng + kg + group_twice[g]);
+  if (ev) atomicAdd(evals, ev);
 }
 
 // ---- eps < 0 or NaN: nobody has a neighbour, not even itself ---------------------------------------
@@ -434,33 +554,36 @@ double l2_threshold(double eps) {
   return t;
 }
 
-// DIM = dimension of the metric (grid and sorted copy); `stride` = doubles per input point
-template <int DIM, int METRIC>
+// GD = dimension of the metric (grid and sorted copy); `stride` = doubles per input point
+template <int GD, int METRIC, bool GROUPED>
 int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, double eps, int min_pts, int32_t cf_in,
                const uint8_t* d_in_classed, int32_t* d_labels, uint8_t* d_is_core, uint8_t* d_is_classed,
-               int32_t* cf_out, int64_t* dist_evals) {
+               int32_t* cf_out, int64_t* dist_evals, const DbscanExt* ext) {
   hipStream_t st = ctx->stream;
   const unsigned nb = vcp_blocks(n, TPB);
-  const int fresh = d_in_classed == nullptr;
+  const int32_t* d_group = GROUPED ? ext->d_group : nullptr;
+  const uint32_t* d_ord = ext ? ext->d_ord : nullptr;
+  const int G = GROUPED ? ext->G : 0;
+  const int glo = GROUPED ? ext->only_lo : 0;
+  const int ghi = GROUPED ? (ext->only_hi < 0 ? G : ext->only_hi) : 0;
 
   // 1. bounds over finite coordinates
   vcp_phase(ctx, "bounds");
   const int rb = (int)vcp_blocks(n, TPB, 1024);
-  VCP_TRY(vcp_ensure(ctx, ctx->b_misc, (size_t)(rb * 6 + 16) * sizeof(double)));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_misc, (size_t)(rb * 6 + 32) * sizeof(double)));
   double* d_part = ctx->b_misc.as<double>();
   double* d_bounds = d_part + (size_t)rb * 6;
-  hipLaunchKernelGGL((k_bounds<DIM>), dim3(rb), dim3(TPB), 0, st, d_coords, n, stride, d_part);
-  hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(64), 0, st, d_part, rb, d_bounds);
+  hipLaunchKernelGGL((k_bounds<GD, GROUPED>), dim3(rb), dim3(TPB), 0, st, d_coords, n, stride, d_group, glo, ghi, d_part);
+  hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(TPB), 0, st, d_part, rb, d_bounds);
   double* h = reinterpret_cast<double*>(ctx->pinned);
   VCP_HIP(ctx, hipMemcpyAsync(h, d_bounds, 6 * sizeof(double), hipMemcpyDeviceToHost, st));
   VCP_HIP(ctx, hipStreamSynchronize(st));
 
   // 2. grid geometry (host): cell edge a hair above eps; coarsen until the cell count fits
   GridP g;
-  g.gdim = DIM;
   double range = 0.0;
   for (int a = 0; a < 3; a++) {
-    double lo = a < DIM ? h[a] : 0.0, hi = a < DIM ? h[3 + a] : 0.0;
+    double lo = a < GD ? h[a] : 0.0, hi = a < GD ? h[3 + a] : 0.0;
     if (!(hi >= lo)) lo = hi = 0.0;  // no finite value on this axis
     g.mn[a] = lo;
     h[a] = lo;
@@ -475,11 +598,11 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   if (budget < (1 << 16)) budget = 1 << 16;
   if (budget > ((int64_t)1 << 28)) budget = (int64_t)1 << 28;
   int64_t ncells = 0;
-  for (int it = 0; it < 200; it++) {
+  for (int it = 0; it < 400; it++) {
     ncells = 1;
     for (int a = 0; a < 3; a++) {
-      double ext = a < DIM ? (h[3 + a] - h[a]) / cellw : 0.0;
-      int64_t d = std::isfinite(ext) ? (int64_t)ext + 1 : 1;
+      double ext_a = a < GD ? (h[3 + a] - h[a]) / cellw : 0.0;
+      int64_t d = std::isfinite(ext_a) ? (int64_t)ext_a + 1 : 1;
       if (d > 1048576) d = 1048576;
       g.D[a] = (int)d;
       ncells *= d;
@@ -489,14 +612,15 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   }
   if (ncells > budget) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "grid does not fit the cell budget");
   g.inv_h = std::isinf(cellw) ? 0.0 : 1.0 / cellw;
+  g.ncells = (uint32_t)ncells;
   const double thr = (METRIC == VCP_L1_2D) ? eps : l2_threshold(eps);
 
-  // 3. histogram + ranks, scan, scatter
-  vcp_phase(ctx, "cell_hist");
+  // 3. workspace
   VCP_TRY(vcp_ensure(ctx, ctx->b_cellcnt, (size_t)(ncells + 2) * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_cellof, (size_t)n * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_rank, (size_t)n * 4));
-  VCP_TRY(vcp_ensure(ctx, ctx->b_sorted, (size_t)n * DIM * 8));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_pos, (size_t)n * 4));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_sorted, (size_t)n * GD * 8));
   VCP_TRY(vcp_ensure(ctx, ctx->b_sidx, (size_t)n * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_flags, (size_t)n));
   VCP_TRY(vcp_ensure(ctx, ctx->b_parent, (size_t)n * 4));
@@ -504,56 +628,78 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   VCP_TRY(vcp_ensure(ctx, ctx->b_seedflag, (size_t)(n + 2) * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_rootcl, (size_t)n * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_clseed, (size_t)n * 4));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_labk, (size_t)n * 4));
+  if (GROUPED) VCP_TRY(vcp_ensure(ctx, ctx->b_sgroup, (size_t)n * 4));
   uint32_t* cellcnt = ctx->b_cellcnt.as<uint32_t>();
   uint32_t* cellof = ctx->b_cellof.as<uint32_t>();
   uint32_t* rank = ctx->b_rank.as<uint32_t>();
+  uint32_t* pos = ctx->b_pos.as<uint32_t>();
   double* sorted = ctx->b_sorted.as<double>();
-  uint32_t* sidx = ctx->b_sidx.as<uint32_t>();
+  uint32_t* sord = ctx->b_sidx.as<uint32_t>();
   uint8_t* flags = ctx->b_flags.as<uint8_t>();
   uint32_t* parent = ctx->b_parent.as<uint32_t>();
   uint32_t* minord = ctx->b_minord.as<uint32_t>();
   uint32_t* seedflag = ctx->b_seedflag.as<uint32_t>();
-  int32_t* rootcl = ctx->b_rootcl.as<int32_t>();
+  uint32_t* rootk = ctx->b_rootcl.as<uint32_t>();
   uint32_t* clseed = ctx->b_clseed.as<uint32_t>();
-  unsigned long long* counters = reinterpret_cast<unsigned long long*>(d_bounds + 8);
+  uint32_t* labk = ctx->b_labk.as<uint32_t>();
+  int32_t* sgroup = GROUPED ? ctx->b_sgroup.as<int32_t>() : nullptr;
+  unsigned long long* counters = reinterpret_cast<unsigned long long*>(d_bounds + 8);  // [4]
+  uint32_t* d_total = reinterpret_cast<uint32_t*>(counters + 2);
 
+  // 4. histogram + ranks, scan, scatter
+  vcp_phase(ctx, "cell_hist");
   VCP_HIP(ctx, hipMemsetAsync(cellcnt, 0, (size_t)(ncells + 1) * 4, st));
-  hipLaunchKernelGGL((k_cell_hist<DIM>), dim3(nb), dim3(TPB), 0, st, d_coords, n, stride, g, cellcnt, cellof, rank);
+  hipLaunchKernelGGL((k_cell_hist<GD, GROUPED>), dim3(nb), dim3(TPB), 0, st, d_coords, n, stride, g, d_group, glo, ghi,
+                     cellcnt, cellof, rank);
   vcp_phase(ctx, "cell_scan");
   VCP_TRY(vcp_exclusive_scan_u32(ctx, cellcnt, cellcnt, ncells + 1, nullptr));
   vcp_phase(ctx, "scatter");
-  hipLaunchKernelGGL((k_scatter<DIM>), dim3(nb), dim3(TPB), 0, st, d_coords, n, stride, cellcnt, cellof, rank,
-                     d_in_classed, sorted, sidx, flags);
+  if (!d_in_classed) VCP_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)n, st));
+  hipLaunchKernelGGL((k_scatter<GD, GROUPED>), dim3(nb), dim3(TPB), 0, st, d_coords, n, stride, cellcnt, cellof, rank,
+                     d_in_classed, d_group, d_ord, pos, sorted, sord, sgroup, flags);
 
-  // 4. core flags
+  // 5. core flags
   vcp_phase(ctx, "core_count");
-  hipLaunchKernelGGL((k_core<DIM, METRIC>), dim3(nb), dim3(TPB), 0, st, sorted, n, g, thr, min_pts, cellcnt, flags);
+  hipLaunchKernelGGL((k_core<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 0, st, sorted, g, thr, min_pts, cellcnt, sgroup,
+                     flags);
 
-  // 5. components of the expanding points
+  // 6. components of the expanding points
   vcp_phase(ctx, "union");
-  hipLaunchKernelGGL(k_init_parent, dim3(nb), dim3(TPB), 0, st, parent, minord, n);
+  hipLaunchKernelGGL(k_init_parent, dim3(nb), dim3(TPB), 0, st, parent, minord, cellcnt, g.ncells);
   VCP_HIP(ctx, hipMemsetAsync(seedflag, 0, (size_t)(n + 1) * 4, st));
   VCP_HIP(ctx, hipMemsetAsync(counters, 0, 4 * sizeof(unsigned long long), st));
-  hipLaunchKernelGGL((k_union<DIM, METRIC>), dim3(nb), dim3(TPB), 0, st, sorted, n, g, thr, cellcnt, flags, parent);
+  hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup, flags,
+                     parent);
   vcp_phase(ctx, "flatten_number");
-  hipLaunchKernelGGL(k_flatten, dim3(nb), dim3(TPB), 0, st, parent, flags, sidx, minord, n);
-  hipLaunchKernelGGL(k_seedflag, dim3(nb), dim3(TPB), 0, st, parent, flags, minord, seedflag, n);
-  uint32_t* d_total = reinterpret_cast<uint32_t*>(counters + 2);
-  VCP_TRY(vcp_exclusive_scan_u32(ctx, seedflag, seedflag, n, d_total));
-  hipLaunchKernelGGL(k_rootid, dim3(nb), dim3(TPB), 0, st, parent, flags, minord, seedflag, cf_in, rootcl, clseed, n);
+  hipLaunchKernelGGL(k_flatten, dim3(nb), dim3(TPB), 0, st, parent, flags, sord, minord, cellcnt, g.ncells);
+  hipLaunchKernelGGL(k_seedflag, dim3(nb), dim3(TPB), 0, st, parent, flags, minord, seedflag, cellcnt, g.ncells);
+  VCP_TRY(vcp_exclusive_scan_u32(ctx, seedflag, seedflag, n + 1, d_total));  // seedflag[n] = total
+  hipLaunchKernelGGL(k_rootk, dim3(nb), dim3(TPB), 0, st, parent, flags, minord, seedflag, rootk, clseed, cellcnt,
+                     g.ncells);
 
-  // 6. labels / border rule / outputs
-  vcp_phase(ctx, "label");
-  hipLaunchKernelGGL((k_label<DIM, METRIC>), dim3(nb), dim3(TPB), 0, st, sorted, n, g, thr, cellcnt, flags, parent,
-                     sidx, rootcl, clseed, cf_in, fresh, d_labels, d_is_core, d_is_classed, counters);
+  // 7. border rule, then outputs in caller order
+  vcp_phase(ctx, "border");
+  if (GROUPED) VCP_HIP(ctx, hipMemsetAsync(ext->d_group_twice, 0, (size_t)G * 4, st));
+  hipLaunchKernelGGL((k_border<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup, flags,
+                     parent, sord, rootk, clseed, labk, counters, GROUPED ? ext->d_group_twice : nullptr);
+  vcp_phase(ctx, "output");
+  hipLaunchKernelGGL((k_output<GROUPED>), dim3(nb), dim3(TPB), 0, st, n, pos, flags, labk, d_in_classed, d_group,
+                     GROUPED ? ext->d_groupstart : nullptr, seedflag, cf_in, d_labels, d_is_core, d_is_classed, counters);
+  if (GROUPED) {
+    hipLaunchKernelGGL(k_group_stats, dim3(vcp_blocks(G, TPB)), dim3(TPB), 0, st, G, glo, ghi, ext->d_groupstart,
+                       seedflag, ext->d_group_twice, ext->d_group_nclus, counters + 3);
+    if (ext->d_group_evals)
+      VCP_HIP(ctx, hipMemcpyAsync(ext->d_group_evals, counters + 3, 8, hipMemcpyDeviceToDevice, st));
+  }
   VCP_HIP(ctx, hipGetLastError());
   unsigned long long* hc = reinterpret_cast<unsigned long long*>(ctx->pinned) + 8;
   VCP_HIP(ctx, hipMemcpyAsync(hc, counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   VCP_TRY(vcp_phase_finish(ctx));
   VCP_HIP(ctx, hipStreamSynchronize(st));
-  uint32_t K = *reinterpret_cast<uint32_t*>(hc + 2);
+  const uint32_t K = *reinterpret_cast<uint32_t*>(hc + 2);
   if (cf_out) *cf_out = cf_in + (int32_t)K;
-  if (dist_evals) *dist_evals = (int64_t)(hc[0] + hc[1] + K) * n;
+  if (dist_evals) *dist_evals = GROUPED ? (int64_t)hc[3] : (int64_t)(hc[0] + hc[1] + K) * n;
   return VCP_OK;
 }
 
@@ -584,21 +730,23 @@ int run_degenerate(vcp_ctx* ctx, int64_t n, int min_pts, int32_t cf_in, const ui
 
 }  // namespace
 
-extern "C" {
-
-int vcp_dbscan_dev(vcp_ctx* ctx, const double* d_coords, int64_t n, int dim, int metric, double eps,
-                   int min_pts, int32_t cf_in, const uint8_t* d_in_classed, int32_t* d_labels,
-                   uint8_t* d_is_core, uint8_t* d_is_classed, int32_t* cf_out, int64_t* dist_evals) {
+int vcp_dbscan_engine(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, int metric, double eps,
+                      int min_pts, int32_t cf_in, const uint8_t* d_in_classed, int32_t* d_labels,
+                      uint8_t* d_is_core, uint8_t* d_is_classed, int32_t* cf_out, int64_t* dist_evals,
+                      const DbscanExt* ext) {
   if (!ctx) return VCP_ERR_ARG;
   if (n < 0) return vcp_fail(ctx, VCP_ERR_ARG, "n < 0");
-  if (dim != 2 && dim != 3) return vcp_fail(ctx, VCP_ERR_ARG, "dim must be 2 or 3");
+  if (stride != 2 && stride != 3) return vcp_fail(ctx, VCP_ERR_ARG, "dim must be 2 or 3");
   if (metric == VCP_SIGNED_SUM_2D)
     return vcp_fail(ctx, VCP_ERR_UNSUPPORTED,
                     "VCP_SIGNED_SUM_2D is the dead DB class (BaseClass/DB.cs:21, FrmMain.cs:38); not built for the GPU");
   if (metric < 0 || metric > 3) return vcp_fail(ctx, VCP_ERR_ARG, "unknown metric %d", metric);
-  if (metric == VCP_L2_3D && dim != 3) return vcp_fail(ctx, VCP_ERR_ARG, "VCP_L2_3D needs dim 3");
+  if (metric == VCP_L2_3D && stride != 3) return vcp_fail(ctx, VCP_ERR_ARG, "VCP_L2_3D needs dim 3");
   if (n >= 0x7FFFFFF0LL) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "n beyond 32-bit indexing");
   if (n > 0 && (!d_coords || !d_labels)) return vcp_fail(ctx, VCP_ERR_ARG, "null buffer");
+  const bool grouped = ext && ext->d_group;
+  if (grouped && (metric != VCP_L1_2D || !ext->d_ord || !ext->d_groupstart || !ext->d_group_twice || d_in_classed))
+    return vcp_fail(ctx, VCP_ERR_ARG, "grouped DBSCAN needs ord, groupstart, group_twice and the L1 metric");
   VCP_TRY(vcp_bind(ctx));
   vcp_phase_reset(ctx);
   if (n == 0) {
@@ -607,15 +755,27 @@ int vcp_dbscan_dev(vcp_ctx* ctx, const double* d_coords, int64_t n, int dim, int
     ctx->last_timing.clear();
     return VCP_OK;
   }
-  if (!(eps >= 0.0))
+  if (!(eps >= 0.0)) {
+    if (grouped) return vcp_fail(ctx, VCP_ERR_ARG, "grouped DBSCAN needs eps >= 0");
     return run_degenerate(ctx, n, min_pts, cf_in, d_in_classed, d_labels, d_is_core, d_is_classed, cf_out, dist_evals);
-#define VCP_RUN(D, M)                                                                                         \
-  return run_dbscan<D, M>(ctx, d_coords, n, dim, eps, min_pts, cf_in, d_in_classed, d_labels, d_is_core, \
-                          d_is_classed, cf_out, dist_evals)
-  if (metric == VCP_L1_2D) VCP_RUN(2, VCP_L1_2D);
-  if (metric == VCP_L2_2D) VCP_RUN(2, VCP_L2_2D);
-  VCP_RUN(3, VCP_L2_3D);
+  }
+#define VCP_RUN(D, M, GR)                                                                                        \
+  return run_dbscan<D, M, GR>(ctx, d_coords, n, stride, eps, min_pts, cf_in, d_in_classed, d_labels, d_is_core, \
+                              d_is_classed, cf_out, dist_evals, ext)
+  if (grouped) VCP_RUN(2, VCP_L1_2D, true);
+  if (metric == VCP_L1_2D) VCP_RUN(2, VCP_L1_2D, false);
+  if (metric == VCP_L2_2D) VCP_RUN(2, VCP_L2_2D, false);
+  VCP_RUN(3, VCP_L2_3D, false);
 #undef VCP_RUN
+}
+
+extern "C" {
+
+int vcp_dbscan_dev(vcp_ctx* ctx, const double* d_coords, int64_t n, int dim, int metric, double eps,
+                   int min_pts, int32_t cf_in, const uint8_t* d_in_classed, int32_t* d_labels,
+                   uint8_t* d_is_core, uint8_t* d_is_classed, int32_t* cf_out, int64_t* dist_evals) {
+  return vcp_dbscan_engine(ctx, d_coords, n, dim, metric, eps, min_pts, cf_in, d_in_classed, d_labels, d_is_core,
+                           d_is_classed, cf_out, dist_evals, nullptr);
 }
 
 int vcp_dbscan(vcp_ctx* ctx, const double* coords, int64_t n, int dim, int metric, double eps, int min_pts,

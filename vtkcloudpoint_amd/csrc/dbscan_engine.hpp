@@ -1,0 +1,24 @@
+// dbscan_engine.hpp -- internal interface of the DBSCAN engine (dbscan.hip), shared with blocks.hip.
+#pragma once
+#include "vcp_ctx.hpp"
+
+// Optional grouping: points are neighbours only inside the same group (the reference's per-block
+// DBImproved instances, FrmMain.cs:2782-2794).  `ord` replaces the original index as "position in the
+// list" for the canonical numbering; it must be a permutation of [0,n) that is group-major, with
+// groupstart[g] the first ord of group g.  Cluster ids restart at cf_in+1 in every group.
+struct DbscanExt {
+  const int32_t* d_group = nullptr;        // [n] by original index; < 0 = point excluded entirely
+  const uint32_t* d_ord = nullptr;         // [n] by original index
+  const uint32_t* d_groupstart = nullptr;  // [G+1]
+  int32_t G = 0;
+  int32_t only_lo = 0, only_hi = -1;       // cluster only groups lo <= g < hi (-1 = G)
+  uint32_t* d_group_twice = nullptr;       // [G] zeroed by the engine; border points queried twice
+  uint32_t* d_group_nclus = nullptr;       // [G] clusters found per group
+  uint64_t* d_group_evals = nullptr;       // [1] sum over clustered groups of n_g*(n_g + K_g + twice_g)
+};
+
+// d_* are device pointers; cf_out / dist_evals host pointers (may be null).  stride = doubles per point.
+int vcp_dbscan_engine(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, int metric, double eps,
+                      int min_pts, int32_t cf_in, const uint8_t* d_in_classed, int32_t* d_labels,
+                      uint8_t* d_is_core, uint8_t* d_is_classed, int32_t* cf_out, int64_t* dist_evals,
+                      const DbscanExt* ext);

@@ -228,7 +228,7 @@ int vcp_create(int device_id, vcp_ctx** out) {
   c->stream = c->own_stream;
   c->pinned_bytes = 1 << 16;
   if (hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocDefault) != hipSuccess) {
-    hipStreamDestroy(c->own_stream);
+    (void)hipStreamDestroy(c->own_stream);
     delete c;
     return vcp_fail(nullptr, VCP_ERR_NOMEM, "pinned scratch allocation failed");
   }
@@ -236,10 +236,13 @@ int vcp_create(int device_id, vcp_ctx** out) {
   return VCP_OK;
 }
 
+void vcp_blocks_state_free(vcp_ctx* ctx);  // blocks.hip
+
 void vcp_destroy(vcp_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  vcp_blocks_state_free(ctx);
   for (DevBuf* b : ctx->bufs)
     if (b->p) (void)hipFree(b->p);
   for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);

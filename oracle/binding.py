@@ -241,3 +241,69 @@ def match(centers, truths, M, max_dist):
                          _p(M, C.c_double), C.c_double(max_dist), _p(mxyz, C.c_double), _p(is_m, C.c_uint8),
                          _p(nearest, C.c_int32), _p(nd, C.c_double), C.byref(cnt)))
     return dict(matched_xyz=mxyz, is_matched=is_m, nearest=nearest, nearest_dist=nd, count=cnt.value)
+
+
+class StagedBlocks:
+    """The oracle's block pipeline in stages, with the same method names as the product's Context
+    (blocks_begin / blocks_share / blocks_cluster_dev / blocks_finish_dev) so that the distributed driver
+    can be exercised on CPU tensors (gloo) in the tests.  Pointers are host addresses here."""
+
+    def __init__(self):
+        self.s = None
+
+    def blocks_begin(self, motor, eps, min_pts, pts_in_cell, small_max=3, device_ptr=None, n=None):
+        motor = _f64(motor, 2)
+        n = len(motor)
+        block_of = np.zeros(n, np.int32)
+        raw = np.zeros(max(n, 1), np.int64)
+        bl = np.zeros(max(n, 1), np.int64)
+        rows, cols, m = C.c_int32(0), C.c_int32(0), C.c_int64(0)
+        _chk(lib().orc_block_partition(_p(motor, C.c_double), C.c_int64(n), int(pts_in_cell), 0,
+                                       _p(block_of, C.c_int32), _p(raw, C.c_int64), _p(bl, C.c_int64), None,
+                                       C.c_int64(0), C.byref(rows), C.byref(cols), C.byref(m)))
+        nblocks = rows.value * cols.value
+        blockstart = np.zeros(nblocks + 1, np.int64)
+        np.add.at(blockstart, block_of[block_of >= 0].astype(np.int64) + 1, 1)
+        blockstart = np.cumsum(blockstart)
+        self.s = dict(motor=motor, n=n, eps=float(eps), min_pts=int(min_pts), small_max=int(small_max),
+                      block_of=block_of, bl=bl, blockstart=blockstart, nblocks=nblocks, m=m.value)
+        return dict(rows=rows.value, cols=cols.value, nblocks=nblocks, m=m.value)
+
+    def blocks_share(self, rank, world):
+        s = self.s
+
+        def cut(r):
+            if r <= 0:
+                return 0
+            if r >= world:
+                return s["nblocks"]
+            target = (s["m"] * r) // world
+            return int(np.searchsorted(s["blockstart"][: s["nblocks"]], target, side="left"))
+
+        lo, hi = cut(rank), cut(rank + 1)
+        return lo, hi, int(s["blockstart"][lo]), int(s["blockstart"][hi])
+
+    def blocks_cluster_dev(self, block_lo, block_hi, ptr):
+        s = self.s
+        local = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int32)), shape=(max(s["m"], 1),))
+        ev = C.c_int64(0)
+        _chk(lib().orc_block_cluster(_p(s["motor"], C.c_double), _p(s["bl"], C.c_int64),
+                                     _p(s["blockstart"], C.c_int64), C.c_int64(block_lo), C.c_int64(block_hi),
+                                     C.c_double(s["eps"]), s["min_pts"], 1, _p(local, C.c_int32), C.byref(ev)))
+        return ev.value
+
+    def blocks_finish_dev(self, local_ptr, evals_blocks, labels_ptr, d_block_of=None, d_merge_order=None):
+        s = self.s
+        local = np.ctypeslib.as_array(C.cast(local_ptr, C.POINTER(C.c_int32)), shape=(max(s["m"], 1),))
+        labels = np.ctypeslib.as_array(C.cast(labels_ptr, C.POINTER(C.c_int32)), shape=(max(s["n"], 1),))
+        order = np.zeros(max(s["n"], 1), np.int64)
+        m = C.c_int64(0)
+        kept, dels, ca = (C.c_int32(0) for _ in range(3))
+        ev = C.c_int64(0)
+        _chk(lib().orc_block_finish(_p(s["motor"], C.c_double), C.c_int64(s["n"]), _p(s["bl"], C.c_int64),
+                                    _p(s["blockstart"], C.c_int64), C.c_int64(s["nblocks"]), _p(local, C.c_int32),
+                                    C.c_double(s["eps"]), s["min_pts"], s["small_max"], 1, C.c_int64(evals_blocks),
+                                    _p(labels, C.c_int32), _p(order, C.c_int64), C.byref(m), C.byref(kept),
+                                    C.byref(dels), C.byref(ca), C.byref(ev)))
+        return dict(m=m.value, kept=kept.value, del_sum=dels.value, cluster_amount=ca.value, evals=ev.value,
+                    order=order[: m.value].copy())

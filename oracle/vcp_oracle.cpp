@@ -441,23 +441,18 @@ int orc_db_literal(const double* coords, int64_t n, int dim, double eps, int min
 }
 
 // -------------------------------------------------------------------------------------
-int orc_block_pipeline(const double* motor, int64_t n, double eps, int min_pts, int pts_in_cell,
-                       int small_max, int use_canonical, int brute_partition, int32_t* labels,
-                       int32_t* block_of, int64_t* merge_order, int64_t* m_out, int32_t* rows_o,
-                       int32_t* cols_o, int32_t* kept_o, int32_t* del_sum_o,
-                       int32_t* cluster_amount_o, int64_t* dist_evals_o) {
+// Block pipeline in three stages (partition / per-block DBImproved / CompleteWork3) so that the staged
+// multi-GPU path can be checked stage by stage; orc_block_pipeline is their composition.
+int orc_block_partition(const double* motor, int64_t n, int pts_in_cell, int brute_partition, int32_t* block_of,
+                        int64_t* raw_o, int64_t* bl_o, int64_t* blockstart_o, int64_t blockstart_cap, int32_t* rows_o,
+                        int32_t* cols_o, int64_t* m_o) {
   if (n < 0) return ORC_ERR_ARG;
   // FrmMain.cs:1224-1227: Min()/Max() on an empty list throw before the Count check of :1228
   if (n == 0) return ORC_ERR_EMPTY;
   if (pts_in_cell <= 0) return ORC_ERR_EMPTY;  // Take(0) -> cell.Max() throws (:1255)
   for (int64_t i = 0; i < n * 2; i++)
     if (!std::isfinite(motor[i])) return ORC_ERR_ARG;
-  // :1219-1223 reset
-  std::vector<uint8_t> classed(n, 0), key(n, 0);
-  for (int64_t i = 0; i < n; i++) {
-    labels[i] = 0;
-    block_of[i] = -1;
-  }
+  for (int64_t i = 0; i < n; i++) block_of[i] = -1;
   // :1224-1227
   double x_Min = motor[0], x_Max = motor[0], y_Min = motor[1], y_Max = motor[1];
   for (int64_t i = 1; i < n; i++) {
@@ -490,6 +485,7 @@ int orc_block_pipeline(const double* motor, int64_t n, double eps, int min_pts, 
   int64_t nblocks = (int64_t)rows * cols;
   if (rows_o) *rows_o = rows;
   if (cols_o) *cols_o = cols;
+  if (blockstart_o && blockstart_cap < nblocks + 1) return ORC_ERR_TOO_LARGE;
 
   // :1259-1285 blocks.  cells[0] = the first `take` points; every other (p,q) is the
   // rectangle filter of Tools.getListByScale2 (BC/Tools.cs:510-513): (lo, hi] on both axes,
@@ -553,23 +549,30 @@ int orc_block_pipeline(const double* motor, int64_t n, double eps, int min_pts, 
   for (int64_t i = 0; i < n; i++)
     if (block_of[i] >= 0) bcount[block_of[i] + 1]++;
   for (int64_t b = 0; b < nblocks; b++) bcount[b + 1] += bcount[b];
-  std::vector<int64_t> bl(bcount[nblocks]);
   {
     std::vector<int64_t> fill(bcount.begin(), bcount.end() - 1);
     for (int64_t t = 0; t < n; t++) {
       int64_t i = raw[t];
-      if (block_of[i] >= 0) bl[fill[block_of[i]]++] = i;
+      if (block_of[i] >= 0) bl_o[fill[block_of[i]]++] = i;
     }
   }
+  if (raw_o) std::copy(raw.begin(), raw.end(), raw_o);
+  if (blockstart_o) std::copy(bcount.begin(), bcount.end(), blockstart_o);
+  if (m_o) *m_o = bcount[nblocks];
+  return ORC_OK;
+}
 
-  // FrmMain.cs:2782-2794 per block: new DBImproved().dbscan(cell, eps, minPts)
+// FrmMain.cs:2782-2794 per block: new DBImproved().dbscan(cell, eps, minPts) for block_lo <= b < block_hi;
+// local[t] = block-local cluster id of bl[t].  Returns the distance evaluations of these blocks.
+int orc_block_cluster(const double* motor, const int64_t* bl, const int64_t* blockstart, int64_t block_lo,
+                      int64_t block_hi, double eps, int min_pts, int use_canonical, int32_t* local,
+                      int64_t* evals_o) {
   int64_t evals = 0;
-  int64_t clusterSum = 1;  // :1346
   std::vector<int32_t> blab;
   std::vector<uint8_t> bcls, bkey;
   std::vector<double> bc;
-  for (int64_t b = 0; b < nblocks; b++) {
-    int64_t s = bcount[b], cnt = bcount[b + 1] - s;
+  for (int64_t b = block_lo; b < block_hi; b++) {
+    int64_t s = blockstart[b], cnt = blockstart[b + 1] - s;
     if (cnt == 0) continue;
     bc.resize(cnt * 2);
     blab.assign(cnt, 0);
@@ -588,25 +591,37 @@ int orc_block_pipeline(const double* motor, int64_t n, double eps, int min_pts, 
       orc_dbscan_literal(bc.data(), cnt, 2, ORC_L1_2D, eps, min_pts, 0, bcls.data(), blab.data(),
                          bkey.data(), &cf, &ev, 0);
     evals += ev;
-    clusterSum += cf;  // :2789
-    for (int64_t t = 0; t < cnt; t++) {
-      labels[bl[s + t]] = blab[t];
-      classed[bl[s + t]] = bcls[t];
-      key[bl[s + t]] = bkey[t];
-    }
+    for (int64_t t = 0; t < cnt; t++) local[s + t] = blab[t];
   }
+  if (evals_o) *evals_o = evals;
+  return ORC_OK;
+}
 
-  // FrmMain.cs:1442-1505 CompleteWork3
-  if (bcount[1] - bcount[0] == 0) return ORC_ERR_INDEX;  // cells[0][0] :1442 (cannot happen: take>=1)
+// FrmMain.cs:1442-1520 CompleteWork3 on the block-local ids `local` [m] (block-major order).
+int orc_block_finish(const double* motor, int64_t n, const int64_t* bl, const int64_t* blockstart, int64_t nblocks,
+                     const int32_t* local, double eps, int min_pts, int small_max, int use_canonical,
+                     int64_t evals_blocks, int32_t* labels, int64_t* merge_order, int64_t* m_out, int32_t* kept_o,
+                     int32_t* del_sum_o, int32_t* cluster_amount_o, int64_t* dist_evals_o) {
+  const int64_t mtot = blockstart[nblocks];
+  for (int64_t i = 0; i < n; i++) labels[i] = 0;
+  for (int64_t t = 0; t < mtot; t++) labels[bl[t]] = local[t];
+  // clusterSum = 1 + sum of per-block clusterAmount (:1346, :2789) = 1 + sum of the largest local id
+  int64_t clusterSum = 1;
+  for (int64_t b = 0; b < nblocks; b++) {
+    int32_t mx = 0;
+    for (int64_t t = blockstart[b]; t < blockstart[b + 1]; t++) mx = std::max(mx, local[t]);
+    clusterSum += mx;
+  }
+  if (blockstart[1] - blockstart[0] == 0) return ORC_ERR_INDEX;  // cells[0][0] :1442 (cannot happen: take>=1)
   int idLast, idNow = 0, id, clusLen = 0, delSum = 0;
   std::vector<int64_t> clusForMerge;
-  clusForMerge.reserve(bl.size());
+  clusForMerge.reserve(mtot);
   std::vector<int64_t> cellsorted;
   for (int64_t b = 0; b < nblocks; b++) {
-    int64_t s = bcount[b], cnt = bcount[b + 1] - s;
+    int64_t s = blockstart[b], cnt = blockstart[b + 1] - s;
     if (cnt == 0) continue;  // :1448
     // :1449-1459 sort by clusterId.  DEVIATION: stable.
-    cellsorted.assign(bl.begin() + s, bl.begin() + s + cnt);
+    cellsorted.assign(bl + s, bl + s + cnt);
     std::stable_sort(cellsorted.begin(), cellsorted.end(),
                      [&](int64_t a, int64_t c) { return labels[a] < labels[c]; });
     idLast = labels[cellsorted[0]];
@@ -652,11 +667,10 @@ int orc_block_pipeline(const double* motor, int64_t n, double eps, int min_pts, 
   int64_t Z = (int64_t)zeroList.size();
   std::vector<double> zc(Z * 2);
   std::vector<int32_t> zl(Z, 0);
-  std::vector<uint8_t> zcl(Z, 0), zk(Z);
+  std::vector<uint8_t> zcl(Z, 0), zk(Z, 0);
   for (int64_t t = 0; t < Z; t++) {
     zc[2 * t] = motor[2 * zeroList[t]];
     zc[2 * t + 1] = motor[2 * zeroList[t] + 1];
-    zk[t] = key[zeroList[t]];
   }
   int32_t cf = cf0;
   int64_t ev = 0;
@@ -666,15 +680,46 @@ int orc_block_pipeline(const double* motor, int64_t n, double eps, int min_pts, 
   else
     orc_dbscan_literal(zc.data(), Z, 2, ORC_L1_2D, eps, min_pts, cf0, zcl.data(), zl.data(), zk.data(),
                        &cf, &ev, 0);
-  evals += ev;
   for (int64_t t = 0; t < Z; t++) labels[zeroList[t]] = zl[t];
   if (cluster_amount_o) *cluster_amount_o = cf;
-  if (dist_evals_o) *dist_evals_o = evals;
+  if (dist_evals_o) *dist_evals_o = evals_blocks + ev;
   int64_t m = 0;
-  for (int64_t pt : rest) merge_order[m++] = pt;
-  for (int64_t pt : zeroList) merge_order[m++] = pt;  // :1517-1520
+  if (merge_order) {
+    for (int64_t pt : rest) merge_order[m++] = pt;
+    for (int64_t pt : zeroList) merge_order[m++] = pt;  // :1517-1520
+  } else {
+    m = (int64_t)rest.size() + Z;
+  }
   if (m_out) *m_out = m;
   return ORC_OK;
+}
+
+int orc_block_pipeline(const double* motor, int64_t n, double eps, int min_pts, int pts_in_cell,
+                       int small_max, int use_canonical, int brute_partition, int32_t* labels,
+                       int32_t* block_of, int64_t* merge_order, int64_t* m_out, int32_t* rows_o,
+                       int32_t* cols_o, int32_t* kept_o, int32_t* del_sum_o,
+                       int32_t* cluster_amount_o, int64_t* dist_evals_o) {
+  int32_t rows = 0, cols = 0;
+  int64_t m = 0;
+  std::vector<int64_t> bl(n > 0 ? n : 1);
+  // two calls: the first sizes rows*cols, the second fills blockstart
+  int rc = orc_block_partition(motor, n, pts_in_cell, brute_partition, block_of, nullptr, bl.data(), nullptr, 0, &rows,
+                               &cols, &m);
+  if (rc) return rc;
+  int64_t nblocks = (int64_t)rows * cols;
+  std::vector<int64_t> blockstart(nblocks + 1, 0);
+  for (int64_t i = 0; i < n; i++)
+    if (block_of[i] >= 0) blockstart[block_of[i] + 1]++;
+  for (int64_t b = 0; b < nblocks; b++) blockstart[b + 1] += blockstart[b];
+  if (rows_o) *rows_o = rows;
+  if (cols_o) *cols_o = cols;
+  std::vector<int32_t> local(m > 0 ? m : 1, 0);
+  int64_t ev = 0;
+  rc = orc_block_cluster(motor, bl.data(), blockstart.data(), 0, nblocks, eps, min_pts, use_canonical, local.data(), &ev);
+  if (rc) return rc;
+  return orc_block_finish(motor, n, bl.data(), blockstart.data(), nblocks, local.data(), eps, min_pts, small_max,
+                          use_canonical, ev, labels, merge_order, m_out, kept_o, del_sum_o, cluster_amount_o,
+                          dist_evals_o);
 }
 
 // -------------------------------------------------------------------------------------

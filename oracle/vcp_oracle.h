@@ -79,6 +79,22 @@ int orc_block_pipeline(const double* motor, int64_t n, double eps, int min_pts, 
                        int32_t* cols, int32_t* kept, int32_t* del_sum, int32_t* cluster_amount,
                        int64_t* dist_evals);
 
+/* The same pipeline in stages (used to check the staged multi-GPU path stage by stage):
+ * partition  -> block_of [n], raw [n] (list order after the sort), bl [m] (block-major list of original
+ *               indices), blockstart [rows*cols+1] (capacity blockstart_cap entries)
+ * cluster    -> local [m] block-local ids for block_lo <= b < block_hi
+ * finish     -> CompleteWork3 from the full `local` array */
+int orc_block_partition(const double* motor, int64_t n, int pts_in_cell, int brute_partition, int32_t* block_of,
+                        int64_t* raw, int64_t* bl, int64_t* blockstart, int64_t blockstart_cap, int32_t* rows,
+                        int32_t* cols, int64_t* m);
+int orc_block_cluster(const double* motor, const int64_t* bl, const int64_t* blockstart, int64_t block_lo,
+                      int64_t block_hi, double eps, int min_pts, int use_canonical, int32_t* local,
+                      int64_t* evals);
+int orc_block_finish(const double* motor, int64_t n, const int64_t* bl, const int64_t* blockstart, int64_t nblocks,
+                     const int32_t* local, double eps, int min_pts, int small_max, int use_canonical,
+                     int64_t evals_blocks, int32_t* labels, int64_t* merge_order, int64_t* m_out, int32_t* kept,
+                     int32_t* del_sum, int32_t* cluster_amount, int64_t* dist_evals);
+
 /* Tools.GetClusList (BC/Tools.cs:162-195): per cluster id 1..K the LINQ Average
  * (sequential binary64 sum, then / count) of X,Y,Z and of motor_x,motor_y over the
  * points visited in `order` (NULL = 0..m-1).  Empty clusters: count 0, NaN rows. */

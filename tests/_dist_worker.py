@@ -1,0 +1,57 @@
+"""Worker for tests/test_distributed_gloo.py: one rank of a world_size-N gloo group on CPU.  The compute
+backend is the oracle's staged block pipeline (CPU); what is under test is the distributed driver
+(vtkcloudpoint_amd/distributed.py): share ranges, padded variable-length all-gather, eval all-reduce,
+slab renumbering."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import binding as O  # noqa: E402
+from vtkcloudpoint_amd import distributed as D  # noqa: E402
+from vtkcloudpoint_amd import synth  # noqa: E402
+
+
+def main():
+    out_path = sys.argv[1]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    d = synth.config_cloud(60_000, seed=21)
+    eps, mp, pic = 0.1, 10, 200
+    res = {}
+    # 1. sharded block pipeline == single-process pipeline
+    be = O.StagedBlocks()
+    r = D.sharded_blocks(be, d["motor"], eps, mp, pic, 3, device="cpu")
+    ref = O.block_pipeline(d["motor"], eps, mp, pic, 3)
+    res["blocks_labels_equal"] = bool(np.array_equal(r["labels"].numpy(), ref["labels"]))
+    res["blocks_meta_equal"] = (r["kept"] == ref["kept"] and r["cluster_amount"] == ref["cluster_amount"]
+                                and r["evals"] == ref["evals"] and r["del_sum"] == ref["del_sum"])
+    res["block_range"] = list(r["block_range"])
+    # 2. variable-length all-gather with an empty slice on one rank
+    m = 1000
+    full = torch.zeros(m, dtype=torch.int32)
+    lo, hi = (0, 0) if rank == 0 else (0, m) if world == 2 else (0, 0)
+    if world > 2:
+        lo, hi = (0, 0) if rank == 0 else ((rank - 1) * m // (world - 1), rank * m // (world - 1))
+    full[lo:hi] = torch.arange(lo, hi, dtype=torch.int32) + 7
+    full = D.allgather_varlen(full, lo, hi, m)
+    res["varlen_ok"] = bool(torch.equal(full, torch.arange(m, dtype=torch.int32) + 7))
+    # 3. slab renumbering offsets
+    off, total = D.exclusive_offsets(10 * (rank + 1), "cpu")
+    res["offset"] = off
+    res["total"] = total
+    res["sum"] = D.allreduce_sum_int(rank + 1, "cpu")
+    with open("%s.%d" % (out_path, rank), "w") as f:
+        json.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,67 @@
+"""Host-side mirrors of the reference's classes: the parts that need no GPU."""
+import numpy as np
+import pytest
+
+from vtkcloudpoint_amd import synth
+from vtkcloudpoint_amd.datamodel import ClusObj, Point3D, motor_array, points_from_arrays, xyz_array
+from vtkcloudpoint_amd.dbscan import DB, DBImproved, NotSupportedError
+from vtkcloudpoint_amd.icp import ICP, Matrix, MException
+from vtkcloudpoint_amd.tools import Tools
+
+
+def test_point3d_and_clusobj_surface():
+    p = Point3D(1, 2, 3, 7, True)  # DataModel.cs:111-119
+    assert (p.X, p.Y, p.Z, p.clusterId, p.ifShown) == (1.0, 2.0, 3.0, 7, True)
+    assert p.isClassed is False and p.isKeyPoint is False and p.motor_x == 0.0
+    c = ClusObj()
+    assert c.li == [] and c.visible is True
+    pts = points_from_arrays(np.array([[1.0, 2.0]]), np.array([[3.0, 4.0, 5.0]]))
+    assert motor_array(pts).tolist() == [[1.0, 2.0]] and xyz_array(pts).tolist() == [[3.0, 4.0, 5.0]]
+
+
+def test_getdisp_and_counter():
+    a, b = Point3D(), Point3D()
+    a.motor_x, a.motor_y, b.motor_x, b.motor_y = 1.0, 1.0, 0.25, 3.0
+    before = DBImproved.iritatorNum
+    assert DBImproved.getDisP(a, b) == 0.75 + 2.0  # |dx| + |dy|, DBImproved.cs:21
+    assert DBImproved.iritatorNum == before + 1
+    a.X, a.Y, b.X, b.Y = 1.0, 1.0, 0.25, 3.0
+    assert DB.getDisP(a, b) == 0.75 - 2.0  # signed sum, DB.cs:21
+    with pytest.raises(NotSupportedError):
+        DB().dbscan([a, b], 1.0, 2)
+
+
+def test_matrix_slice():
+    A = Matrix(3, 3)
+    for i in range(3):
+        for j in range(3):
+            A[i, j] = i * 3 + j
+    I3 = Matrix.IdentityMatrix(3, 3)
+    assert (A * I3).mat == A.mat and Matrix.Transpose(A)[0, 2] == A[2, 0] and Matrix.TR(A) == 12.0
+    assert (A + A).mat == (2 * A).mat and (A - A).mat == [0.0] * 9
+    v = Matrix(3, 1)
+    v[0, 0], v[1, 0], v[2, 0] = 1, 2, 3
+    assert (A * v).mat == [8.0, 26.0, 44.0]
+    with pytest.raises(MException):
+        Matrix.Multiply(v, A)
+    with pytest.raises(IndexError):
+        A[9, 0]  # flat-array bounds only, like the C# (Matrix.cs:30-34; ICP.cs:170-174 runs into it)
+    R = Matrix(3, 3)
+    ICP.CalculateRotation([1.0, 0, 0, 0], R)
+    assert R.mat == Matrix.IdentityMatrix(3, 3).mat
+
+
+def test_scale_filters():
+    pts = points_from_arrays(np.array([[0.0, 0.0], [1.0, 1.0], [2.0, 2.0]]), np.array([[0.0, 0, 0], [1.0, 1, 0], [2.0, 2, 0]]))
+    assert len(Tools.getListByScale2(pts, 0.0, 0.0, 1.0, 1.0)) == 1  # strict > on the low edge, <= on the high
+    assert len(Tools.getListByScale(pts, -1.0, -1.0, 2.0, 2.0)) == 3
+
+
+def test_synth_is_deterministic_and_quantised():
+    a, b = synth.config_cloud(20000, seed=2), synth.config_cloud(20000, seed=2)
+    assert np.array_equal(a["motor"], b["motor"]) and np.array_equal(a["xyz"], b["xyz"])
+    assert np.array_equal(a["motor"] * 1024, np.round(a["motor"] * 1024))
+    assert synth.splitmix64(1, 0, 3).tolist() == synth.splitmix64(1, 0, 5)[:3].tolist()
+    assert synth.splitmix64(1, 2, 3).tolist() == synth.splitmix64(1, 0, 5)[2:].tolist()  # counter-based
+    c = synth.config_icp(nd=1000, nm=20, jitter=0.0)
+    assert np.allclose(c["data"] @ c["R_true"].T + c["T_true"], c["model"][np.arange(1000) % 20], atol=1e-12)

@@ -17,9 +17,10 @@
 //   minord  [nin] u32        per root: smallest list position in the component (= the seed)
 //   seedflag[n+1] u32        1 at the list position of each seed, then its exclusive scan
 //   rootk   [nin] u32        per root: rank of its seed among all seeds; clseed [K]: seed per rank
-//   labk    [nin] u32        per point: 1 + seed rank of its final cluster, 0 = none
+//   labk    [nin] u32        per point: (1 + seed rank of its final cluster, 0 = none) << 2 | core | classed<<1
 // Passes: bounds -> cell_hist -> scan -> scatter -> core -> union -> flatten/number -> border -> output.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -246,13 +247,23 @@ __device__ __forceinline__ void for_rows(const int* cc, const GridP& g, const ui
     }
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  The neighbour-search kernels
+// remap the block index so that each XCD walks ONE contiguous eighth of the cell-ordered arrays: a point's
+// neighbour rows are then (mostly) in its own XCD's 4 MiB L2.  Speed only, never correctness.
+__device__ __forceinline__ int64_t xcd_block(unsigned nblocks) {
+  const unsigned b = blockIdx.x;
+  const unsigned per = nblocks >> 3;  // blocks per XCD in the remapped part
+  if (b >= (per << 3)) return b;      // tail blocks keep their index
+  return (int64_t)(b & 7u) * per + (b >> 3);
+}
+
 // ---- core flags (region query with early exit at min_pts) ---------------------------------------
 template <int GD, int METRIC, bool GROUPED>
 __global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted, GridP g, double thr, int min_pts,
                                              const uint32_t* __restrict__ cellstart,
                                              const int32_t* __restrict__ sgroup, uint8_t* __restrict__ flags) {
   const uint32_t nin = cellstart[g.ncells];
-  int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  int64_t p = xcd_block(gridDim.x) * TPB + threadIdx.x;
   if (p >= nin) return;
   double q[3];
   int cc[3];
@@ -285,6 +296,12 @@ __global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted,
 // valid; every structural change goes through a device-scope CAS, which is the arbiter.
 __device__ __forceinline__ uint32_t ld_parent(const uint32_t* parent, uint32_t x) {
   return __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// plain (L1-cacheable) load that the optimiser may not fold: neighbouring parent[] entries share cache
+// lines, and a stale value is still a valid (older) ancestor link
+__device__ __forceinline__ uint32_t ld_parent_cached(const uint32_t* parent, uint32_t x) {
+  return __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
 __device__ __forceinline__ uint32_t uf_root(const uint32_t* parent, uint32_t x) {
@@ -325,9 +342,9 @@ template <int GD, int METRIC, bool GROUPED>
 __global__ __launch_bounds__(TPB) void k_union(const double* __restrict__ sorted, GridP g, double thr,
                                               const uint32_t* __restrict__ cellstart,
                                               const int32_t* __restrict__ sgroup, const uint8_t* __restrict__ flags,
-                                              uint32_t* __restrict__ parent) {
+                                              uint32_t* __restrict__ parent, int dbg) {
   const uint32_t nin = cellstart[g.ncells];
-  int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  int64_t p = xcd_block(gridDim.x) * TPB + threadIdx.x;
   if (p >= nin) return;
   if (!(flags[p] & F_EXPAND)) return;
   double q[3];
@@ -346,9 +363,16 @@ __global__ __launch_bounds__(TPB) void k_union(const double* __restrict__ sorted
       double r[3];
       load_pt<GD>(sorted, j, r);
       if (!within<METRIC>(q, r, thr)) continue;
-      uint32_t rj = uf_root(parent, j);
+      if (dbg == 1) { rp = min(rp, j); continue; }
+      uint32_t pj = ld_parent_cached(parent, j);
+      if (dbg == 2) { rp = min(rp, pj); continue; }
+      if (pj == rp) continue;  // already under my root (the common case inside a cluster)
+      uint32_t rj = uf_root(parent, pj);
       rp = uf_root(parent, rp);
       if (rj != rp) rp = uf_link(parent, rp, rj);
+      // compress j's pointer (rp is now an ancestor of j); cached store, same-XCD readers profit
+      if (dbg != 3 && pj != rp && j != rp)
+        __hip_atomic_store(&parent[j], rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
     return true;
   });
@@ -423,7 +447,7 @@ __global__ __launch_bounds__(TPB) void k_border(const double* __restrict__ sorte
                                                uint32_t* __restrict__ labk, unsigned long long* __restrict__ counters,
                                                uint32_t* __restrict__ group_twice) {
   const uint32_t nin = cellstart[g.ncells];
-  int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  int64_t p = xcd_block(gridDim.x) * TPB + threadIdx.x;
   unsigned twice = 0;
   if (p < nin) {
     const uint8_t fl = flags[p];
@@ -457,7 +481,7 @@ __global__ __launch_bounds__(TPB) void k_border(const double* __restrict__ sorte
         if (GROUPED) atomicAdd(&group_twice[myg], 1u);
       }
     }
-    labk[p] = out;
+    labk[p] = (out << 2) | ((fl & F_CORE) ? 1u : 0u) | ((fl & F_CLASSED) ? 2u : 0u);
   }
   if (!GROUPED) {
     unsigned long long m2 = __ballot(twice);
@@ -468,7 +492,7 @@ __global__ __launch_bounds__(TPB) void k_border(const double* __restrict__ sorte
 // ---- outputs in caller order (coalesced writes, gather from the sorted arrays) ------------------------
 template <bool GROUPED>
 __global__ __launch_bounds__(TPB) void k_output(int64_t n, const uint32_t* __restrict__ pos,
-                                               const uint8_t* __restrict__ flags, const uint32_t* __restrict__ labk,
+                                               const uint32_t* __restrict__ labk,
                                                const uint8_t* __restrict__ in_classed, const int32_t* __restrict__ group,
                                                const uint32_t* __restrict__ groupstart,
                                                const uint32_t* __restrict__ seedscan, int32_t cf_in,
@@ -477,6 +501,7 @@ __global__ __launch_bounds__(TPB) void k_output(int64_t n, const uint32_t* __res
                                                unsigned long long* __restrict__ counters) {
   int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
   unsigned unclassed = 0;
+  (void)counters;
   if (i < n) {
     const uint32_t p = pos[i];
     if (p == NONE) {  // excluded from this call
@@ -484,21 +509,33 @@ __global__ __launch_bounds__(TPB) void k_output(int64_t n, const uint32_t* __res
       if (is_core) is_core[i] = 0;
       if (is_classed) is_classed[i] = in_classed ? in_classed[i] : 0;
     } else {
-      const uint8_t fl = flags[p];
-      const uint32_t k1 = labk[p];
+      const uint32_t w = labk[p];
+      const uint32_t k1 = w >> 2;
+      const bool core = w & 1u, classed = w & 2u;
       int32_t lab = 0;
       if (k1) {
         uint32_t base = GROUPED ? seedscan[groupstart[group[i]]] : 0u;
         lab = cf_in + (int32_t)(k1 - base);
       }
       if (lab != 0 || !in_classed) labels[i] = lab;
-      if (is_core) is_core[i] = ((fl & F_CORE) && !(fl & F_CLASSED)) ? 1 : 0;
-      if (is_classed) is_classed[i] = ((fl & F_CLASSED) || lab != 0) ? 1 : 0;
-      if (!(fl & F_CLASSED)) unclassed = 1;
+      if (is_core) is_core[i] = (core && !classed) ? 1 : 0;
+      if (is_classed) is_classed[i] = (classed || lab != 0) ? 1 : 0;
+      if (!classed) unclassed = 1;
     }
   }
-  unsigned long long m1 = __ballot(unclassed);
-  if ((threadIdx.x & 63) == 0 && m1) atomicAdd(&counters[0], (unsigned long long)__popcll(m1));
+  // points not classed on entry: only worth counting when the caller passed in_classed (otherwise it is
+  // every clustered point); one atomic per workgroup, spread over 32 slots (a single hot word serialises)
+  if (in_classed) {
+    __shared__ unsigned wcnt[TPB / 64];
+    unsigned long long m1 = __ballot(unclassed);
+    if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = (unsigned)__popcll(m1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned t = 0;
+      for (int k = 0; k < TPB / 64; k++) t += wcnt[k];
+      if (t) atomicAdd(&counters[4 + (blockIdx.x & 31)], (unsigned long long)t);
+    }
+  }
 }
 
 // per-group statistics: clusters per group and the op counter of the per-block DBImproved instances
@@ -570,7 +607,7 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   // 1. bounds over finite coordinates
   vcp_phase(ctx, "bounds");
   const int rb = (int)vcp_blocks(n, TPB, 1024);
-  VCP_TRY(vcp_ensure(ctx, ctx->b_misc, (size_t)(rb * 6 + 32) * sizeof(double)));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_misc, (size_t)(rb * 6 + 64) * sizeof(double)));
   double* d_part = ctx->b_misc.as<double>();
   double* d_bounds = d_part + (size_t)rb * 6;
   hipLaunchKernelGGL((k_bounds<GD, GROUPED>), dim3(rb), dim3(TPB), 0, st, d_coords, n, stride, d_group, glo, ghi, d_part);
@@ -644,7 +681,8 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   uint32_t* clseed = ctx->b_clseed.as<uint32_t>();
   uint32_t* labk = ctx->b_labk.as<uint32_t>();
   int32_t* sgroup = GROUPED ? ctx->b_sgroup.as<int32_t>() : nullptr;
-  unsigned long long* counters = reinterpret_cast<unsigned long long*>(d_bounds + 8);  // [4]
+  // [0] unused, [1] border points queried twice, [2] seed total (u32), [3] grouped evals, [4..36) unclassed slots
+  unsigned long long* counters = reinterpret_cast<unsigned long long*>(d_bounds + 8);
   uint32_t* d_total = reinterpret_cast<uint32_t*>(counters + 2);
 
   // 4. histogram + ranks, scan, scatter
@@ -668,9 +706,9 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   vcp_phase(ctx, "union");
   hipLaunchKernelGGL(k_init_parent, dim3(nb), dim3(TPB), 0, st, parent, minord, cellcnt, g.ncells);
   VCP_HIP(ctx, hipMemsetAsync(seedflag, 0, (size_t)(n + 1) * 4, st));
-  VCP_HIP(ctx, hipMemsetAsync(counters, 0, 4 * sizeof(unsigned long long), st));
+  VCP_HIP(ctx, hipMemsetAsync(counters, 0, 36 * sizeof(unsigned long long), st));
   hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup, flags,
-                     parent);
+                     parent, getenv("VCP_DBG_UNION") ? atoi(getenv("VCP_DBG_UNION")) : 0);
   vcp_phase(ctx, "flatten_number");
   hipLaunchKernelGGL(k_flatten, dim3(nb), dim3(TPB), 0, st, parent, flags, sord, minord, cellcnt, g.ncells);
   hipLaunchKernelGGL(k_seedflag, dim3(nb), dim3(TPB), 0, st, parent, flags, minord, seedflag, cellcnt, g.ncells);
@@ -684,7 +722,7 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   hipLaunchKernelGGL((k_border<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup, flags,
                      parent, sord, rootk, clseed, labk, counters, GROUPED ? ext->d_group_twice : nullptr);
   vcp_phase(ctx, "output");
-  hipLaunchKernelGGL((k_output<GROUPED>), dim3(nb), dim3(TPB), 0, st, n, pos, flags, labk, d_in_classed, d_group,
+  hipLaunchKernelGGL((k_output<GROUPED>), dim3(nb), dim3(TPB), 0, st, n, pos, labk, d_in_classed, d_group,
                      GROUPED ? ext->d_groupstart : nullptr, seedflag, cf_in, d_labels, d_is_core, d_is_classed, counters);
   if (GROUPED) {
     hipLaunchKernelGGL(k_group_stats, dim3(vcp_blocks(G, TPB)), dim3(TPB), 0, st, G, glo, ghi, ext->d_groupstart,
@@ -694,12 +732,17 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   }
   VCP_HIP(ctx, hipGetLastError());
   unsigned long long* hc = reinterpret_cast<unsigned long long*>(ctx->pinned) + 8;
-  VCP_HIP(ctx, hipMemcpyAsync(hc, counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  VCP_HIP(ctx, hipMemcpyAsync(hc, counters, 36 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   VCP_TRY(vcp_phase_finish(ctx));
   VCP_HIP(ctx, hipStreamSynchronize(st));
   const uint32_t K = *reinterpret_cast<uint32_t*>(hc + 2);
+  unsigned long long unclassed = (unsigned long long)n;  // nobody classed on entry
+  if (d_in_classed) {
+    unclassed = 0;
+    for (int k = 0; k < 32; k++) unclassed += hc[4 + k];
+  }
   if (cf_out) *cf_out = cf_in + (int32_t)K;
-  if (dist_evals) *dist_evals = GROUPED ? (int64_t)hc[3] : (int64_t)(hc[0] + hc[1] + K) * n;
+  if (dist_evals) *dist_evals = GROUPED ? (int64_t)hc[3] : (int64_t)(unclassed + hc[1] + K) * n;
   return VCP_OK;
 }
 
@@ -742,7 +785,7 @@ int vcp_dbscan_engine(vcp_ctx* ctx, const double* d_coords, int64_t n, int strid
                     "VCP_SIGNED_SUM_2D is the dead DB class (BaseClass/DB.cs:21, FrmMain.cs:38); not built for the GPU");
   if (metric < 0 || metric > 3) return vcp_fail(ctx, VCP_ERR_ARG, "unknown metric %d", metric);
   if (metric == VCP_L2_3D && stride != 3) return vcp_fail(ctx, VCP_ERR_ARG, "VCP_L2_3D needs dim 3");
-  if (n >= 0x7FFFFFF0LL) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "n beyond 32-bit indexing");
+  if (n >= 0x3FFFFFF0LL) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "n beyond 30-bit indexing");
   if (n > 0 && (!d_coords || !d_labels)) return vcp_fail(ctx, VCP_ERR_ARG, "null buffer");
   const bool grouped = ext && ext->d_group;
   if (grouped && (metric != VCP_L1_2D || !ext->d_ord || !ext->d_groupstart || !ext->d_group_twice || d_in_classed))

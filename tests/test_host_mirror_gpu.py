@@ -99,3 +99,14 @@ def test_go_hell_icp_and_matching(vcp_ctx, oracle):
     mt = Matcher(cen, c["model"], M, vcp_ctx)
     assert mt.RecorrectMatchingPtsByDistance(0.01) == 50
     assert [p.matchNum for p in cen] == [i % 100 for i in range(50)]
+
+
+def test_cpp_host_mirror_demo():
+    """vtkcloudpoint_amd/host/cpp/vcp_host.hpp (the C++ mirror of the C# classes) against hand-derived answers."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vtkcloudpoint_amd", "host", "cpp",
+                       "host_demo")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "PASS host_demo" in out.stdout, out.stdout + out.stderr

@@ -4,7 +4,7 @@
 set -e
 export TMPDIR=/tmp
 OUT=${1:-gpurun_out/prof}
-ARGS=${2:---steps 5 --warmup 2 --no-cpu-baseline --no-extras}
+ARGS=${2:---steps 5 --warmup 2 --no-cpu-baseline}
 rm -rf "$OUT"; mkdir -p "$OUT"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py $ARGS > "$OUT/bench_stats.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py $ARGS > "$OUT/bench_fetch.log" 2>&1

@@ -20,7 +20,8 @@ from collections import defaultdict
 PHASE_OF = {
     "k_bounds": "bounds", "k_bounds_final": "bounds", "k_cell_hist": "cell_hist", "k_scatter": "scatter",
     "k_core": "core_count", "k_union": "union", "k_init_parent": "union", "k_flatten": "flatten_number",
-    "k_seedflag": "flatten_number", "k_rootid": "flatten_number", "k_label": "label",
+    "k_seedflag": "flatten_number", "k_rootid": "flatten_number", "k_rootk": "flatten_number", "k_label": "label",
+    "k_border": "border", "k_output": "output",
     "k_icp_pass": "icp", "k_icp_final": "icp",
 }
 
@@ -37,13 +38,18 @@ def main():
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     os.makedirs(out_dir, exist_ok=True)
     rows = []
-    for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
+    def newest(pattern):
+        # gpurun merges outputs into the local directory without deleting older runs: take the latest file
+        fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+        return fs[-1:]
+
+    for f in newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
         with open(f) as fh:
             rows = list(csv.DictReader(fh))
     pmc = {}
     for key, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         acc = defaultdict(list)
-        for f in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
+        for f in newest(os.path.join(src, sub, "*", "*_counter_collection.csv")):
             with open(f) as fh:
                 for r in csv.DictReader(fh):
                     if r["Counter_Name"] == key:

@@ -159,21 +159,41 @@ __global__ __launch_bounds__(BT) void k_minmax2_part(const double* __restrict__ 
     for (int k = 0; k < 5; k++) part[(size_t)blockIdx.x * 5 + k] = sm[0][k];
   }
 }
-__global__ void k_minmax2_final(const double* __restrict__ part, int nb, double* __restrict__ out) {
-  if (threadIdx.x != 0) return;
-  double a = part[0], b = part[1], c = part[2], d = part[3], e = part[4];
-  for (int k = 1; k < nb; k++) {
+__global__ __launch_bounds__(BT) void k_minmax2_final(const double* __restrict__ part, int nb, double* __restrict__ out) {
+  double a = INFINITY, b = -INFINITY, c = INFINITY, d = -INFINITY, e = 0;
+  for (int k = threadIdx.x; k < nb; k += BT) {
     a = fmin(a, part[k * 5]);
     b = fmax(b, part[k * 5 + 1]);
     c = fmin(c, part[k * 5 + 2]);
     d = fmax(d, part[k * 5 + 3]);
     e += part[k * 5 + 4];
   }
-  out[0] = a;
-  out[1] = b;
-  out[2] = c;
-  out[3] = d;
-  out[4] = e;
+  __shared__ double sm[BT / 64][5];
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  a = wmin(a);
+  b = wmax(b);
+  c = wmin(c);
+  d = wmax(d);
+#pragma unroll
+  for (int k = 32; k > 0; k >>= 1) e += __shfl_down(e, k, 64);
+  if (lane == 0) {
+    sm[w][0] = a;
+    sm[w][1] = b;
+    sm[w][2] = c;
+    sm[w][3] = d;
+    sm[w][4] = e;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < BT / 64; k++) {
+      sm[0][0] = fmin(sm[0][0], sm[k][0]);
+      sm[0][1] = fmax(sm[0][1], sm[k][1]);
+      sm[0][2] = fmin(sm[0][2], sm[k][2]);
+      sm[0][3] = fmax(sm[0][3], sm[k][3]);
+      sm[0][4] += sm[k][4];
+    }
+    for (int k = 0; k < 5; k++) out[k] = sm[0][k];
+  }
 }
 
 // FrmMain.cs:1231-1232: d = Math.Max(x - x_Min, y - y_Min); non-negative, so the IEEE bit pattern orders it
@@ -401,7 +421,7 @@ int blocks_begin(vcp_ctx* ctx, const double* d_motor_in, bool from_host, const d
   double* part = s->misc.as<double>();
   double* out = part + (size_t)rb * 5;
   hipLaunchKernelGGL(k_minmax2_part, dim3(rb), dim3(BT), 0, st, motor, n, part);
-  hipLaunchKernelGGL(k_minmax2_final, dim3(1), dim3(64), 0, st, part, rb, out);
+  hipLaunchKernelGGL(k_minmax2_final, dim3(1), dim3(BT), 0, st, part, rb, out);
   double* h = reinterpret_cast<double*>(ctx->pinned);
   VCP_HIP(ctx, hipMemcpyAsync(h, out, 5 * 8, hipMemcpyDeviceToHost, st));
   VCP_HIP(ctx, hipStreamSynchronize(st));

@@ -17,7 +17,7 @@
 namespace {
 
 constexpr int ITPB = 256;
-constexpr int ICP_MAX_BLOCKS = 2048;
+constexpr int ICP_MAX_BLOCKS = 1024;
 
 struct Xf {
   double R[9];
@@ -89,15 +89,35 @@ __global__ __launch_bounds__(ITPB) void k_icp_pass(const double* __restrict__ mo
   }
 }
 
-// fixed-order reduction of the block partials: 16 lanes x 4 interleaved chains, combined in order
-__global__ __launch_bounds__(64) void k_icp_final(const double* __restrict__ partial, int nb, double* __restrict__ out) {
-  const int k = threadIdx.x & 15, c = threadIdx.x >> 4;  // 4 chains per sum
-  double v = 0.0;
-  for (int b = c; b < nb; b += 4) v += partial[(size_t)b * 16 + k];
-  __shared__ double sm[4][16];
-  sm[c][k] = v;
+// fixed-order reduction of the block partials: thread t adds blocks t, t+256, ... in order, then a fixed
+// shuffle/LDS tree over the 256 threads (same order every run -> bitwise reproducible sums)
+__global__ __launch_bounds__(ITPB) void k_icp_final(const double* __restrict__ partial, int nb, double* __restrict__ out) {
+  double s[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) s[k] = 0.0;
+  for (int b = threadIdx.x; b < nb; b += ITPB) {
+    const double2* row = reinterpret_cast<const double2*>(partial + (size_t)b * 16);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      double2 v = row[k];
+      s[2 * k] += v.x;
+      s[2 * k + 1] += v.y;
+    }
+  }
+  __shared__ double sm[ITPB / 64][16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    double v = wave_sum(s[k]);
+    if (lane == 0) sm[w][k] = v;
+  }
   __syncthreads();
-  if (threadIdx.x < 16) out[k] = ((sm[0][k] + sm[1][k]) + sm[2][k]) + sm[3][k];
+  if (threadIdx.x < 16) {
+    double v = sm[0][threadIdx.x];
+#pragma unroll
+    for (int k = 1; k < ITPB / 64; k++) v += sm[k][threadIdx.x];
+    out[threadIdx.x] = v;
+  }
 }
 
 // ---- host: Horn's unit-quaternion closed form ---------------------------------------------------
@@ -185,7 +205,7 @@ int icp_pass(vcp_ctx* ctx, const double* d_model, int64_t nm, const double* d_da
   double* part = ctx->b_icp_part.as<double>();
   double* out = part + (size_t)ICP_MAX_BLOCKS * 16;
   hipLaunchKernelGGL(k_icp_pass, dim3(nb), dim3(ITPB), 0, st, d_model, (int)nm, d_data, nd, xf, part, d_nn);
-  hipLaunchKernelGGL(k_icp_final, dim3(1), dim3(64), 0, st, part, nb, out);
+  hipLaunchKernelGGL(k_icp_final, dim3(1), dim3(ITPB), 0, st, part, nb, out);
   double* h = reinterpret_cast<double*>(ctx->pinned);
   VCP_HIP(ctx, hipMemcpyAsync(h, out, 16 * sizeof(double), hipMemcpyDeviceToHost, st));
   VCP_HIP(ctx, hipStreamSynchronize(st));

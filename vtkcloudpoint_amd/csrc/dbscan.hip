@@ -31,6 +31,13 @@ namespace {
 constexpr int TPB = 256;
 constexpr uint8_t F_CORE = 1, F_CLASSED = 2, F_EXPAND = 4;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
+// candidates examined per loop trip in the neighbour-search kernels (independent loads in flight per lane)
+#ifndef VCP_UNR2
+#define VCP_UNR2 4
+#endif
+#ifndef VCP_UNR3
+#define VCP_UNR3 2
+#endif
 
 struct GridP {
   double mn[3];
@@ -269,16 +276,28 @@ __global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted,
   int cc[3];
   load_pt<GD>(sorted, p, q);
   cell_of<GD>(q, g, cc);
+  constexpr int UNR = GD == 3 ? VCP_UNR3 : VCP_UNR2;
   const int32_t myg = GROUPED ? sgroup[p] : 0;
   int cnt = 0;
   for_rows<GD>(cc, g, cellstart, [&](uint32_t s, uint32_t e) {
-    for (uint32_t j = s; j < e; j++) {
-      if (GROUPED && sgroup[j] != myg) continue;
-      double r[3];
-      load_pt<GD>(sorted, j, r);
-      if (within<METRIC>(q, r, thr)) {
-        if (++cnt >= min_pts) return false;
+    // batches of UNR candidates: UNR independent loads in flight per lane (the loop is latency bound), the
+    // early exit is checked once per batch
+    for (uint32_t j = s; j < e; j += UNR) {
+      double r[UNR][3];
+      int32_t gj[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; u++) {
+        const uint32_t jj = min(j + u, e - 1);
+        load_pt<GD>(sorted, jj, r[u]);
+        if (GROUPED) gj[u] = sgroup[jj];
       }
+#pragma unroll
+      for (int u = 0; u < UNR; u++) {
+        bool ok = (j + u < e) && within<METRIC>(q, r[u], thr);
+        if (GROUPED) ok = ok && gj[u] == myg;
+        cnt += ok ? 1 : 0;
+      }
+      if (cnt >= min_pts) return false;
     }
     return true;
   });
@@ -338,6 +357,66 @@ __global__ __launch_bounds__(TPB) void k_init_parent(uint32_t* __restrict__ pare
   minord[p] = NONE;
 }
 
+// Phase 1 of the component build: every expanding point links to its SMALLEST expanding neighbour within eps
+// (rows and positions are visited in increasing order, so the first hit is the smallest: early exit).  Plain
+// stores, no atomics: each thread writes only its own parent and pointers only go down, so this is a forest.
+template <int GD, int METRIC, bool GROUPED>
+__global__ __launch_bounds__(TPB) void k_union_init(const double* __restrict__ sorted, GridP g, double thr,
+                                                   const uint32_t* __restrict__ cellstart,
+                                                   const int32_t* __restrict__ sgroup,
+                                                   const uint8_t* __restrict__ flags, uint32_t* __restrict__ parent) {
+  const uint32_t nin = cellstart[g.ncells];
+  int64_t p = xcd_block(gridDim.x) * TPB + threadIdx.x;
+  if (p >= nin) return;
+  if (!(flags[p] & F_EXPAND)) return;
+  double q[3];
+  int cc[3];
+  load_pt<GD>(sorted, p, q);
+  cell_of<GD>(q, g, cc);
+  constexpr int UNR = GD == 3 ? VCP_UNR3 : VCP_UNR2;
+  const int32_t myg = GROUPED ? sgroup[p] : 0;
+  const uint32_t me = (uint32_t)p;
+  uint32_t first = me;
+  for_rows<GD>(cc, g, cellstart, [&](uint32_t s, uint32_t e) {
+    if (s >= me) return false;
+    if (e > me) e = me;
+    for (uint32_t j0 = s; j0 < e; j0 += UNR) {
+      double rr[UNR][3];
+      bool cand[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; u++) {
+        const uint32_t jj = min(j0 + u, e - 1);
+        cand[u] = (j0 + u < e) && (flags[jj] & F_EXPAND);
+        if (GROUPED) cand[u] = cand[u] && sgroup[jj] == myg;
+        load_pt<GD>(sorted, jj, rr[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; u++)
+        if (first == me && cand[u] && within<METRIC>(q, rr[u], thr)) first = j0 + u;
+      if (first != me) return false;
+    }
+    return true;
+  });
+  if (first != me) parent[me] = first;
+}
+
+// Phase 2: flatten the phase-1 forest (no atomics; a racing reader sees an older or a newer ancestor)
+__global__ __launch_bounds__(TPB) void k_flatten0(uint32_t* __restrict__ parent, const uint8_t* __restrict__ flags,
+                                                 const uint32_t* __restrict__ cellstart, uint32_t ncells) {
+  const uint32_t nin = cellstart[ncells];
+  int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (p >= nin || !(flags[p] & F_EXPAND)) return;
+  uint32_t r = (uint32_t)p, x = ld_parent_cached(parent, r);
+  if (x == r) return;
+  while (x != r) {
+    r = x;
+    x = ld_parent_cached(parent, r);
+  }
+  __hip_atomic_store(&parent[p], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+// Phase 3: all remaining core-core edges.  Most are already inside one phase-1/2 tree (one cached load tells);
+// the rest hook tree roots together with a device-scope CAS.
 template <int GD, int METRIC, bool GROUPED>
 __global__ __launch_bounds__(TPB) void k_union(const double* __restrict__ sorted, GridP g, double thr,
                                               const uint32_t* __restrict__ cellstart,
@@ -351,18 +430,27 @@ __global__ __launch_bounds__(TPB) void k_union(const double* __restrict__ sorted
   int cc[3];
   load_pt<GD>(sorted, p, q);
   cell_of<GD>(q, g, cc);
+  constexpr int UNR = GD == 3 ? VCP_UNR3 : VCP_UNR2;
   const int32_t myg = GROUPED ? sgroup[p] : 0;
   const uint32_t me = (uint32_t)p;
-  uint32_t rp = me;  // cached root of my tree
+  uint32_t rp = parent[me];  // cached root of my tree (flattened by phase 2)
   for_rows<GD>(cc, g, cellstart, [&](uint32_t s, uint32_t e) {
     if (s >= me) return false;  // rows come in increasing position: nothing below me is left
     if (e > me) e = me;         // every undirected edge is handled by its larger endpoint
-    for (uint32_t j = s; j < e; j++) {
-      if (!(flags[j] & F_EXPAND)) continue;
-      if (GROUPED && sgroup[j] != myg) continue;
-      double r[3];
-      load_pt<GD>(sorted, j, r);
-      if (!within<METRIC>(q, r, thr)) continue;
+    for (uint32_t j0 = s; j0 < e; j0 += UNR) {
+      double rr[UNR][3];
+      bool cand[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; u++) {
+        const uint32_t jj = min(j0 + u, e - 1);
+        cand[u] = (j0 + u < e) && (flags[jj] & F_EXPAND);
+        if (GROUPED) cand[u] = cand[u] && sgroup[jj] == myg;
+        load_pt<GD>(sorted, jj, rr[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; u++) {
+      const uint32_t j = j0 + u;
+      if (!cand[u] || !within<METRIC>(q, rr[u], thr)) continue;
       if (dbg == 1) { rp = min(rp, j); continue; }
       uint32_t pj = ld_parent_cached(parent, j);
       if (dbg == 2) { rp = min(rp, pj); continue; }
@@ -373,6 +461,7 @@ __global__ __launch_bounds__(TPB) void k_union(const double* __restrict__ sorted
       // compress j's pointer (rp is now an ancestor of j); cached store, same-XCD readers profit
       if (dbg != 3 && pj != rp && j != rp)
         __hip_atomic_store(&parent[j], rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
     }
     return true;
   });
@@ -459,18 +548,27 @@ __global__ __launch_bounds__(TPB) void k_border(const double* __restrict__ sorte
       int cc[3];
       load_pt<GD>(sorted, p, q);
       cell_of<GD>(q, g, cc);
+      constexpr int UNR = GD == 3 ? VCP_UNR3 : VCP_UNR2;
       const int32_t myg = GROUPED ? sgroup[p] : 0;
       uint32_t mx = 0, mnk = NONE;
       for_rows<GD>(cc, g, cellstart, [&](uint32_t s, uint32_t e) {
-        for (uint32_t j = s; j < e; j++) {
-          if (!(flags[j] & F_EXPAND)) continue;
-          if (GROUPED && sgroup[j] != myg) continue;
-          double r[3];
-          load_pt<GD>(sorted, j, r);
-          if (within<METRIC>(q, r, thr)) {
-            uint32_t k = rootk[parent[j]];
-            mx = max(mx, k + 1u);
-            mnk = min(mnk, k);
+        for (uint32_t j0 = s; j0 < e; j0 += UNR) {
+          double rr[UNR][3];
+          bool cand[UNR];
+#pragma unroll
+          for (int u = 0; u < UNR; u++) {
+            const uint32_t jj = min(j0 + u, e - 1);
+            cand[u] = (j0 + u < e) && (flags[jj] & F_EXPAND);
+            if (GROUPED) cand[u] = cand[u] && sgroup[jj] == myg;
+            load_pt<GD>(sorted, jj, rr[u]);
+          }
+#pragma unroll
+          for (int u = 0; u < UNR; u++) {
+            if (cand[u] && within<METRIC>(q, rr[u], thr)) {
+              uint32_t k = rootk[parent[j0 + u]];
+              mx = max(mx, k + 1u);
+              mnk = min(mnk, k);
+            }
           }
         }
         return true;
@@ -707,8 +805,15 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   hipLaunchKernelGGL(k_init_parent, dim3(nb), dim3(TPB), 0, st, parent, minord, cellcnt, g.ncells);
   VCP_HIP(ctx, hipMemsetAsync(seedflag, 0, (size_t)(n + 1) * 4, st));
   VCP_HIP(ctx, hipMemsetAsync(counters, 0, 36 * sizeof(unsigned long long), st));
+  const int dbg = getenv("VCP_DBG_UNION") ? atoi(getenv("VCP_DBG_UNION")) : 0;
+  // phases 1-2 pay for their extra search pass in 2-D (3 rows); in 3-D (9 rows) they do not
+  if (GD == 2 && dbg != 4) {
+    hipLaunchKernelGGL((k_union_init<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup,
+                       flags, parent);
+    hipLaunchKernelGGL(k_flatten0, dim3(nb), dim3(TPB), 0, st, parent, flags, cellcnt, g.ncells);
+  }
   hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup, flags,
-                     parent, getenv("VCP_DBG_UNION") ? atoi(getenv("VCP_DBG_UNION")) : 0);
+                     parent, dbg);
   vcp_phase(ctx, "flatten_number");
   hipLaunchKernelGGL(k_flatten, dim3(nb), dim3(TPB), 0, st, parent, flags, sord, minord, cellcnt, g.ncells);
   hipLaunchKernelGGL(k_seedflag, dim3(nb), dim3(TPB), 0, st, parent, flags, minord, seedflag, cellcnt, g.ncells);

@@ -1,8 +1,12 @@
 // vcp_ctx.hip -- context lifetime, workspace, per-phase hipEvent timing and the u32 scan used
 // by the grid build and the canonical cluster numbering.
-#include "vcp_ctx.hpp"
+#include <string.h>  // rocprim's texture_cache_iterator.hpp calls ::memset without including it
+
+#include <rocprim/rocprim.hpp>
 
 #include <cstring>
+
+#include "vcp_ctx.hpp"
 
 static thread_local std::string g_create_err;
 
@@ -74,113 +78,13 @@ int vcp_phase_finish(vcp_ctx* ctx) {
 }
 
 // ------------------------------------------------------------------------------------------
-// exclusive scan (u32): 256 threads x 8 items per block, three phases, recursive on block sums
+// exclusive scan (u32): rocPRIM's single-pass decoupled look-back scan (a plain library primitive); the
+// grand total, when asked for, is out[n-1] + in[n-1] (the last input is saved first: in-place is allowed)
 // ------------------------------------------------------------------------------------------
 namespace {
-constexpr int SCAN_T = 256;
-constexpr int SCAN_I = 8;
-constexpr int SCAN_B = SCAN_T * SCAN_I;
-
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t t = __shfl_up(v, d, 64);
-    if (lane >= d) v += t;
-  }
-  return v;
-}
-
-// block-wide exclusive scan of one value per thread; returns exclusive prefix, *total = block sum
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* total) {
-  __shared__ uint32_t wsum[SCAN_T / 64];
-  __shared__ uint32_t wtot;
-  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  uint32_t inc = wave_incl_scan(v, lane);
-  if (lane == 63) wsum[w] = inc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t a = 0;
-    for (int i = 0; i < SCAN_T / 64; i++) {
-      uint32_t t = wsum[i];
-      wsum[i] = a;
-      a += t;
-    }
-    wtot = a;
-  }
-  __syncthreads();
-  uint32_t r = inc - v + wsum[w];
-  *total = wtot;
-  __syncthreads();
-  return r;
-}
-
-__global__ __launch_bounds__(SCAN_T) void k_scan_reduce(const uint32_t* __restrict__ in, int64_t n,
-                                                       uint32_t* __restrict__ bsum) {
-  int64_t base = (int64_t)blockIdx.x * SCAN_B;
-  uint32_t s = 0;
-#pragma unroll
-  for (int k = 0; k < SCAN_I; k++) {
-    int64_t i = base + (int64_t)k * SCAN_T + threadIdx.x;
-    if (i < n) s += in[i];
-  }
-  uint32_t tot;
-  block_excl_scan(s, &tot);
-  if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
-}
-
-// single block: exclusive scan of m values (m <= SCAN_B), total to *d_total
-__global__ __launch_bounds__(SCAN_T) void k_scan_small(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                      int m, uint32_t* __restrict__ d_total) {
-  uint32_t v[SCAN_I];
-  uint32_t s = 0;
-  int base = threadIdx.x * SCAN_I;
-#pragma unroll
-  for (int k = 0; k < SCAN_I; k++) {
-    v[k] = (base + k < m) ? in[base + k] : 0u;
-    s += v[k];
-  }
-  uint32_t tot;
-  uint32_t pre = block_excl_scan(s, &tot);
-#pragma unroll
-  for (int k = 0; k < SCAN_I; k++) {
-    if (base + k < m) out[base + k] = pre;
-    pre += v[k];
-  }
-  if (threadIdx.x == 0 && d_total) *d_total = tot;
-}
-
-__global__ __launch_bounds__(SCAN_T) void k_scan_apply(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                      int64_t n, const uint32_t* __restrict__ boff) {
-  // thread t owns SCAN_I consecutive items so that the per-thread serial scan is in order
-  int64_t base = (int64_t)blockIdx.x * SCAN_B + (int64_t)threadIdx.x * SCAN_I;
-  uint32_t v[SCAN_I];
-  uint32_t s = 0;
-#pragma unroll
-  for (int k = 0; k < SCAN_I; k++) {
-    v[k] = (base + k < n) ? in[base + k] : 0u;
-    s += v[k];
-  }
-  uint32_t tot;
-  uint32_t pre = block_excl_scan(s, &tot) + boff[blockIdx.x];
-#pragma unroll
-  for (int k = 0; k < SCAN_I; k++) {
-    if (base + k < n) out[base + k] = pre;
-    pre += v[k];
-  }
-}
-
-int scan_rec(vcp_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, int64_t n, uint32_t* d_total,
-             uint32_t* tmp) {
-  if (n <= SCAN_B) {
-    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(SCAN_T), 0, ctx->stream, d_in, d_out, (int)n, d_total);
-    return VCP_OK;
-  }
-  int64_t nb = (n + SCAN_B - 1) / SCAN_B;
-  uint32_t* bsum = tmp;
-  hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_T), 0, ctx->stream, d_in, n, bsum);
-  VCP_TRY(scan_rec(ctx, bsum, bsum, nb, d_total, tmp + nb));
-  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(SCAN_T), 0, ctx->stream, d_in, d_out, n, bsum);
-  return VCP_OK;
+__global__ void k_scan_total(const uint32_t* __restrict__ out_last, const uint32_t* __restrict__ in_last,
+                             uint32_t* __restrict__ total) {
+  *total = *out_last + *in_last;
 }
 }  // namespace
 
@@ -190,13 +94,15 @@ int vcp_exclusive_scan_u32(vcp_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, 
     if (d_total) VCP_HIP(ctx, hipMemsetAsync(d_total, 0, 4, ctx->stream));
     return VCP_OK;
   }
-  size_t need = 0;
-  for (int64_t m = n; m > SCAN_B;) {
-    m = (m + SCAN_B - 1) / SCAN_B;
-    need += (size_t)m;
-  }
-  VCP_TRY(vcp_ensure(ctx, ctx->b_scan_tmp, (need + 16) * sizeof(uint32_t)));
-  VCP_TRY(scan_rec(ctx, d_in, d_out, n, d_total, ctx->b_scan_tmp.as<uint32_t>()));
+  size_t tb = 0;
+  VCP_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, d_in, d_out, 0u, (size_t)n, rocprim::plus<uint32_t>(), ctx->stream));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_scan_tmp, tb + 64));
+  uint32_t* saved = reinterpret_cast<uint32_t*>(ctx->b_scan_tmp.as<char>() + ((tb + 15) & ~(size_t)15));
+  if (d_total)
+    VCP_HIP(ctx, hipMemcpyAsync(saved, d_in + (n - 1), 4, hipMemcpyDeviceToDevice, ctx->stream));
+  VCP_HIP(ctx, rocprim::exclusive_scan(ctx->b_scan_tmp.p, tb, d_in, d_out, 0u, (size_t)n, rocprim::plus<uint32_t>(),
+                                       ctx->stream));
+  if (d_total) hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(1), 0, ctx->stream, d_out + (n - 1), saved, d_total);
   VCP_HIP(ctx, hipGetLastError());
   return VCP_OK;
 }

@@ -29,7 +29,7 @@
 namespace {
 
 constexpr int TPB = 256;
-constexpr uint8_t F_CORE = 1, F_CLASSED = 2, F_EXPAND = 4;
+constexpr uint8_t F_CORE = 1, F_CLASSED = 2, F_EXPAND = 4, F_BCAND = 8;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 // candidates examined per loop trip in the neighbour-search kernels (independent loads in flight per lane)
 #ifndef VCP_UNR2
@@ -264,22 +264,95 @@ __device__ __forceinline__ int64_t xcd_block(unsigned nblocks) {
   return (int64_t)(b & 7u) * per + (b >> 3);
 }
 
+// Work lists.  Only ~1/4 of the points are expanding and only the non-core points that have a neighbour
+// need the border search; running those kernels over all positions leaves most lanes idle.  k_core therefore
+// appends positions to two compact lists (one wave-aggregated atomic per wave).  Each list is split into 8
+// regions = eighths of the position range, and list kernels map block b to region b & 7: blocks b and b+8
+// share an XCD, so a region's data stays in one XCD's L2.  Append order is arbitrary; no result depends on it.
+struct WorkList {
+  uint32_t* list;        // positions, in position order
+  const uint32_t* scan;  // [nblk+1] exclusive scan of the per-block entry counts (blocks of TPB positions)
+  uint32_t perblk;       // blocks per region
+  uint32_t nblk;
+};
+
+// position handled by this thread of a list kernel, or NONE
+__device__ __forceinline__ uint32_t wl_fetch(const WorkList& w) {
+  const uint32_t r = blockIdx.x & 7u;
+  const uint32_t lo = w.scan[min(r * w.perblk, w.nblk)], hi = w.scan[min((r + 1u) * w.perblk, w.nblk)];
+  const uint32_t t = lo + (blockIdx.x >> 3) * TPB + threadIdx.x;
+  if (t >= hi) return NONE;
+  return w.list[t];
+}
+
+// per-block entry counts of both lists (no atomics: one slot per block of TPB positions)
+__device__ __forceinline__ void wl_count(bool isE, bool isB, uint32_t blk, uint32_t* __restrict__ cntE,
+                                         uint32_t* __restrict__ cntB) {
+  __shared__ unsigned wc[2][TPB / 64];
+  const unsigned long long mE = __ballot(isE), mB = __ballot(isB);
+  if ((threadIdx.x & 63) == 0) {
+    wc[0][threadIdx.x >> 6] = (unsigned)__popcll(mE);
+    wc[1][threadIdx.x >> 6] = (unsigned)__popcll(mB);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned a = 0, b = 0;
+    for (int k = 0; k < TPB / 64; k++) {
+      a += wc[0][k];
+      b += wc[1][k];
+    }
+    cntE[blk] = a;
+    cntB[blk] = b;
+  }
+}
+
+// fill both lists from the flags, in position order
+__global__ __launch_bounds__(TPB) void k_wl_fill(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ cellstart,
+                                                uint32_t ncells, const uint32_t* __restrict__ scanE,
+                                                const uint32_t* __restrict__ scanB, uint32_t* __restrict__ listE,
+                                                uint32_t* __restrict__ listB) {
+  const uint32_t nin = cellstart[ncells];
+  const int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  const uint8_t fl = p < nin ? flags[p] : 0;
+  const bool isE = fl & F_EXPAND, isB = fl & F_BCAND;
+  __shared__ unsigned wo[2][TPB / 64];
+  const unsigned long long mE = __ballot(isE), mB = __ballot(isB);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) {
+    wo[0][w] = (unsigned)__popcll(mE);
+    wo[1][w] = (unsigned)__popcll(mB);
+  }
+  __syncthreads();
+  unsigned oE = scanE[blockIdx.x], oB = scanB[blockIdx.x];
+  for (int k = 0; k < w; k++) {
+    oE += wo[0][k];
+    oB += wo[1][k];
+  }
+  const unsigned long long below = (1ull << lane) - 1ull;
+  if (isE) listE[oE + (unsigned)__popcll(mE & below)] = (uint32_t)p;
+  if (isB) listB[oB + (unsigned)__popcll(mB & below)] = (uint32_t)p;
+}
+
 // ---- core flags (region query with early exit at min_pts) ---------------------------------------
 template <int GD, int METRIC, bool GROUPED>
 __global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted, GridP g, double thr, int min_pts,
                                              const uint32_t* __restrict__ cellstart,
-                                             const int32_t* __restrict__ sgroup, uint8_t* __restrict__ flags) {
+                                             const int32_t* __restrict__ sgroup, uint8_t* __restrict__ flags,
+                                             uint32_t* __restrict__ blkE, uint32_t* __restrict__ blkB) {
   const uint32_t nin = cellstart[g.ncells];
-  int64_t p = xcd_block(gridDim.x) * TPB + threadIdx.x;
-  if (p >= nin) return;
-  double q[3];
-  int cc[3];
-  load_pt<GD>(sorted, p, q);
-  cell_of<GD>(q, g, cc);
+  const int64_t blk = xcd_block(gridDim.x);
+  int64_t p = blk * TPB + threadIdx.x;
+  const bool live = p < nin;
+  double q[3] = {0, 0, 0};
+  int cc[3] = {0, 0, 0};
+  if (live) {
+    load_pt<GD>(sorted, p, q);
+    cell_of<GD>(q, g, cc);
+  }
   constexpr int UNR = GD == 3 ? VCP_UNR3 : VCP_UNR2;
-  const int32_t myg = GROUPED ? sgroup[p] : 0;
+  const int32_t myg = (GROUPED && live) ? sgroup[p] : 0;
   int cnt = 0;
-  for_rows<GD>(cc, g, cellstart, [&](uint32_t s, uint32_t e) {
+  if (live) for_rows<GD>(cc, g, cellstart, [&](uint32_t s, uint32_t e) {
     // batches of UNR candidates: UNR independent loads in flight per lane (the loop is latency bound), the
     // early exit is checked once per batch
     for (uint32_t j = s; j < e; j += UNR) {
@@ -301,12 +374,23 @@ __global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted,
     }
     return true;
   });
-  uint8_t fl = flags[p];
-  if (cnt >= min_pts) {
+  uint8_t fl = live ? flags[p] : 0;
+  bool isE = false, isB = false;
+  if (!live) {
+  } else if (cnt >= min_pts) {
     fl |= F_CORE;
-    if (!(fl & F_CLASSED)) fl |= F_EXPAND;
+    if (!(fl & F_CLASSED)) {
+      fl |= F_EXPAND;
+      isE = true;
+    } else {
+      isB = true;  // classed core point: takes the largest adjacent cluster like a border point
+    }
+  } else {
+    isB = cnt > 1;  // no early exit happened, so cnt is exact: 1 = nobody but itself within eps
   }
-  flags[p] = fl;
+  if (isB) fl |= F_BCAND;
+  if (live) flags[p] = fl;
+  wl_count(isE, isB, (uint32_t)blk, blkE, blkB);
 }
 
 // ---- union-find over expanding points -------------------------------------------------------------
@@ -364,11 +448,10 @@ template <int GD, int METRIC, bool GROUPED>
 __global__ __launch_bounds__(TPB) void k_union_init(const double* __restrict__ sorted, GridP g, double thr,
                                                    const uint32_t* __restrict__ cellstart,
                                                    const int32_t* __restrict__ sgroup,
-                                                   const uint8_t* __restrict__ flags, uint32_t* __restrict__ parent) {
-  const uint32_t nin = cellstart[g.ncells];
-  int64_t p = xcd_block(gridDim.x) * TPB + threadIdx.x;
-  if (p >= nin) return;
-  if (!(flags[p] & F_EXPAND)) return;
+                                                   const uint8_t* __restrict__ flags, uint32_t* __restrict__ parent,
+                                                   WorkList wlE) {
+  const uint32_t p = wl_fetch(wlE);
+  if (p == NONE) return;
   double q[3];
   int cc[3];
   load_pt<GD>(sorted, p, q);
@@ -421,11 +504,9 @@ template <int GD, int METRIC, bool GROUPED>
 __global__ __launch_bounds__(TPB) void k_union(const double* __restrict__ sorted, GridP g, double thr,
                                               const uint32_t* __restrict__ cellstart,
                                               const int32_t* __restrict__ sgroup, const uint8_t* __restrict__ flags,
-                                              uint32_t* __restrict__ parent, int dbg) {
-  const uint32_t nin = cellstart[g.ncells];
-  int64_t p = xcd_block(gridDim.x) * TPB + threadIdx.x;
-  if (p >= nin) return;
-  if (!(flags[p] & F_EXPAND)) return;
+                                              uint32_t* __restrict__ parent, int dbg, WorkList wlE) {
+  const uint32_t p = wl_fetch(wlE);
+  if (p == NONE) return;
   double q[3];
   int cc[3];
   load_pt<GD>(sorted, p, q);
@@ -534,16 +615,13 @@ __global__ __launch_bounds__(TPB) void k_border(const double* __restrict__ sorte
                                                const uint32_t* __restrict__ parent, const uint32_t* __restrict__ sord,
                                                const uint32_t* __restrict__ rootk, const uint32_t* __restrict__ clseed,
                                                uint32_t* __restrict__ labk, unsigned long long* __restrict__ counters,
-                                               uint32_t* __restrict__ group_twice) {
-  const uint32_t nin = cellstart[g.ncells];
-  int64_t p = xcd_block(gridDim.x) * TPB + threadIdx.x;
+                                               uint32_t* __restrict__ group_twice, WorkList wlB) {
+  const uint32_t p = wl_fetch(wlB);
   unsigned twice = 0;
-  if (p < nin) {
+  if (p != NONE) {
     const uint8_t fl = flags[p];
     uint32_t out = 0;
-    if (fl & F_EXPAND) {
-      out = rootk[parent[p]] + 1u;
-    } else {
+    {
       double q[3];
       int cc[3];
       load_pt<GD>(sorted, p, q);
@@ -585,6 +663,20 @@ __global__ __launch_bounds__(TPB) void k_border(const double* __restrict__ sorte
     unsigned long long m2 = __ballot(twice);
     if ((threadIdx.x & 63) == 0 && m2) atomicAdd(&counters[1], (unsigned long long)__popcll(m2));
   }
+}
+
+// labk of every position the border list does not cover: expanding points take their component's rank,
+// everything else (no neighbour within eps) keeps 0
+__global__ __launch_bounds__(TPB) void k_labk_rest(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ parent,
+                                                  const uint32_t* __restrict__ rootk, uint32_t* __restrict__ labk,
+                                                  const uint32_t* __restrict__ cellstart, uint32_t ncells) {
+  const uint32_t nin = cellstart[ncells];
+  int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (p >= nin) return;
+  const uint8_t fl = flags[p];
+  if (fl & F_BCAND) return;
+  const uint32_t out = (fl & F_EXPAND) ? rootk[parent[p]] + 1u : 0u;
+  labk[p] = (out << 2) | ((fl & F_CORE) ? 1u : 0u) | ((fl & F_CLASSED) ? 2u : 0u);
 }
 
 // ---- outputs in caller order (coalesced writes, gather from the sorted arrays) ------------------------
@@ -795,10 +887,25 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   hipLaunchKernelGGL((k_scatter<GD, GROUPED>), dim3(nb), dim3(TPB), 0, st, d_coords, n, stride, cellcnt, cellof, rank,
                      d_in_classed, d_group, d_ord, pos, sorted, sord, sgroup, flags);
 
-  // 5. core flags
+  // 5. core flags + work lists (expanding points; non-core points that have a neighbour)
   vcp_phase(ctx, "core_count");
+  WorkList wlE, wlB;
+  VCP_TRY(vcp_ensure(ctx, ctx->b_wl, ((size_t)n * 2 + (size_t)(nb + 2) * 2) * 4 + 256));
+  uint32_t* blkE = ctx->b_wl.as<uint32_t>();
+  uint32_t* blkB = blkE + (nb + 2);
+  wlE.list = blkB + (nb + 2);
+  wlB.list = wlE.list + n;
+  wlE.scan = blkE;
+  wlB.scan = blkB;
+  wlE.nblk = wlB.nblk = nb;
+  wlE.perblk = wlB.perblk = (nb + 7) / 8;
+  VCP_HIP(ctx, hipMemsetAsync(blkE, 0, (size_t)(nb + 2) * 2 * 4, st));
+  const unsigned nbl = 8u * wlE.perblk;  // list kernels: block b -> region b & 7 (a region has <= perblk*TPB entries)
   hipLaunchKernelGGL((k_core<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 0, st, sorted, g, thr, min_pts, cellcnt, sgroup,
-                     flags);
+                     flags, blkE, blkB);
+  VCP_TRY(vcp_exclusive_scan_u32(ctx, blkE, blkE, (int64_t)nb + 1, nullptr));
+  VCP_TRY(vcp_exclusive_scan_u32(ctx, blkB, blkB, (int64_t)nb + 1, nullptr));
+  hipLaunchKernelGGL(k_wl_fill, dim3(nb), dim3(TPB), 0, st, flags, cellcnt, g.ncells, blkE, blkB, wlE.list, wlB.list);
 
   // 6. components of the expanding points
   vcp_phase(ctx, "union");
@@ -808,12 +915,12 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   const int dbg = getenv("VCP_DBG_UNION") ? atoi(getenv("VCP_DBG_UNION")) : 0;
   // phases 1-2 pay for their extra search pass in 2-D (3 rows); in 3-D (9 rows) they do not
   if (GD == 2 && dbg != 4) {
-    hipLaunchKernelGGL((k_union_init<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup,
-                       flags, parent);
+    hipLaunchKernelGGL((k_union_init<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup,
+                       flags, parent, wlE);
     hipLaunchKernelGGL(k_flatten0, dim3(nb), dim3(TPB), 0, st, parent, flags, cellcnt, g.ncells);
   }
-  hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup, flags,
-                     parent, dbg);
+  hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup, flags,
+                     parent, dbg, wlE);
   vcp_phase(ctx, "flatten_number");
   hipLaunchKernelGGL(k_flatten, dim3(nb), dim3(TPB), 0, st, parent, flags, sord, minord, cellcnt, g.ncells);
   hipLaunchKernelGGL(k_seedflag, dim3(nb), dim3(TPB), 0, st, parent, flags, minord, seedflag, cellcnt, g.ncells);
@@ -824,8 +931,9 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   // 7. border rule, then outputs in caller order
   vcp_phase(ctx, "border");
   if (GROUPED) VCP_HIP(ctx, hipMemsetAsync(ext->d_group_twice, 0, (size_t)G * 4, st));
-  hipLaunchKernelGGL((k_border<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup, flags,
-                     parent, sord, rootk, clseed, labk, counters, GROUPED ? ext->d_group_twice : nullptr);
+  hipLaunchKernelGGL(k_labk_rest, dim3(nb), dim3(TPB), 0, st, flags, parent, rootk, labk, cellcnt, g.ncells);
+  hipLaunchKernelGGL((k_border<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup, flags,
+                     parent, sord, rootk, clseed, labk, counters, GROUPED ? ext->d_group_twice : nullptr, wlB);
   vcp_phase(ctx, "output");
   hipLaunchKernelGGL((k_output<GROUPED>), dim3(nb), dim3(TPB), 0, st, n, pos, labk, d_in_classed, d_group,
                      GROUPED ? ext->d_groupstart : nullptr, seedflag, cf_in, d_labels, d_is_core, d_is_classed, counters);

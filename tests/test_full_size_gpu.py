@@ -1,0 +1,74 @@
+"""BASELINE.json full sizes on the GPU: the 10M-point C4 cloud.  Direct bit-exact comparison with the
+order-free oracle (the literal O(n^2) port cannot run at this size) plus size-independent properties:
+permutation invariance of the core set / noise set / core partition, idempotence of a second call on the
+already-classed cloud, and agreement of the block pipeline with the oracle at full size."""
+import numpy as np
+import pytest
+
+from vtkcloudpoint_amd import _native as N
+from vtkcloudpoint_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c4():
+    return synth.config_cloud(10_000_000, seed=4)
+
+
+@pytest.fixture(scope="module")
+def c4_gpu(vcp_ctx, c4):
+    return vcp_ctx.dbscan(c4["motor"], c4["eps_l1"], c4["min_pts"], N.L1_2D)
+
+
+def test_c4_10m_bit_exact_vs_canonical_oracle(c4, c4_gpu, oracle):
+    o = oracle.dbscan(c4["motor"], c4["eps_l1"], c4["min_pts"], oracle.L1_2D)
+    assert np.array_equal(c4_gpu["labels"], o["labels"])
+    assert np.array_equal(c4_gpu["is_core"], o["is_key"]) and np.array_equal(c4_gpu["is_classed"], o["classed"])
+    assert c4_gpu["cf"] == o["cf"] and c4_gpu["evals"] == o["evals"]
+
+
+def test_c4_permutation_invariance(vcp_ctx, c4, c4_gpu):
+    n = len(c4["motor"])
+    perm = synth.permutation(99, n)
+    g2 = vcp_ctx.dbscan(c4["motor"][perm], c4["eps_l1"], c4["min_pts"], N.L1_2D)
+    core1, core2 = c4_gpu["is_core"][perm].astype(bool), g2["is_core"].astype(bool)
+    assert np.array_equal(core1, core2)                                  # same core set
+    assert np.array_equal(c4_gpu["labels"][perm] == 0, g2["labels"] == 0)  # same noise set
+    assert g2["cf"] == c4_gpu["cf"]                                      # same number of clusters
+    a, b = c4_gpu["labels"][perm][core1].astype(np.int64), g2["labels"][core2].astype(np.int64)
+    pairs = np.unique(a * (g2["cf"] + 1) + b)                            # core partition: ids in bijection
+    assert len(pairs) == len(np.unique(a)) == len(np.unique(b))
+    # numbering rule: cluster k's smallest member index increases with k
+    lab = g2["labels"]
+    core_idx = np.nonzero(core2)[0]
+    first = np.full(g2["cf"] + 1, n, np.int64)
+    np.minimum.at(first, lab[core_idx], core_idx)
+    assert np.all(np.diff(first[1:]) > 0)
+
+
+def test_c4_second_call_is_idempotent(vcp_ctx, c4, c4_gpu):
+    """DBImproved never resets isClassed: calling dbscan again on the classed cloud (cf carried over) finds no
+    new seed; classed core points only re-take the largest adjacent id -- nothing changes."""
+    g = vcp_ctx.dbscan(c4["motor"], c4["eps_l1"], c4["min_pts"], N.L1_2D, c4_gpu["cf"], c4_gpu["is_classed"],
+                       c4_gpu["labels"])
+    assert g["cf"] == c4_gpu["cf"]
+    assert np.array_equal(g["labels"] != 0, c4_gpu["labels"] != 0)
+    assert not g["is_core"][c4_gpu["is_classed"].astype(bool)].any()  # classed points are never re-queried
+
+
+def test_c4_block_pipeline_vs_oracle(vcp_ctx, c4, oracle):
+    o = oracle.block_pipeline(c4["motor"], 0.07, 7, 200, 3)  # the reference UI defaults
+    g = vcp_ctx.dbscan_blocks(c4["motor"], 0.07, 7, 200, 3)
+    for k in ("labels", "block_of", "order"):
+        assert np.array_equal(g[k], o[k]), k
+    for k in ("rows", "cols", "kept", "del_sum", "cluster_amount", "evals"):
+        assert g[k] == o[k], k
+
+
+def test_l2_3d_4m_vs_oracle(vcp_ctx, oracle):
+    """The Euclidean 3-D form (DBImproved.cs:20) at 4M points (the CPU oracle needs ~9 s per million here)."""
+    d = synth.config_cloud(4_000_000, seed=6)
+    o = oracle.dbscan(d["xyz"], d["eps_l2"], d["min_pts"], oracle.L2_3D)
+    g = vcp_ctx.dbscan(d["xyz"], d["eps_l2"], d["min_pts"], N.L2_3D)
+    assert np.array_equal(g["labels"], o["labels"]) and g["cf"] == o["cf"] and g["evals"] == o["evals"]

@@ -483,6 +483,45 @@ __global__ __launch_bounds__(TPB) void k_union_init(const double* __restrict__ s
   if (first != me) parent[me] = first;
 }
 
+// Phase 2b: every tree root looks at ALL its expanding neighbours (both directions) and, if one of them
+// sits in a tree with a smaller root, hangs itself under that root.  Only the root's own thread writes its
+// parent and pointers only decrease: still a forest, no atomics.  Repeated with a flatten in between this
+// merges neighbouring trees Boruvka-style, so that phase 3 finds almost every edge already inside one tree.
+template <int GD, int METRIC, bool GROUPED>
+__global__ __launch_bounds__(TPB) void k_root_hook(const double* __restrict__ sorted, GridP g, double thr,
+                                                  const uint32_t* __restrict__ cellstart,
+                                                  const int32_t* __restrict__ sgroup, const uint8_t* __restrict__ flags,
+                                                  uint32_t* __restrict__ parent, WorkList wlE) {
+  const uint32_t p = wl_fetch(wlE);
+  if (p == NONE) return;
+  if (ld_parent_cached(parent, p) != p) return;  // not a root
+  double q[3];
+  int cc[3];
+  load_pt<GD>(sorted, p, q);
+  cell_of<GD>(q, g, cc);
+  constexpr int UNR = GD == 3 ? VCP_UNR3 : VCP_UNR2;
+  const int32_t myg = GROUPED ? sgroup[p] : 0;
+  uint32_t best = p;
+  for_rows<GD>(cc, g, cellstart, [&](uint32_t s, uint32_t e) {
+    for (uint32_t j0 = s; j0 < e; j0 += UNR) {
+      double rr[UNR][3];
+      bool cand[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; u++) {
+        const uint32_t jj = min(j0 + u, e - 1);
+        cand[u] = (j0 + u < e) && (flags[jj] & F_EXPAND);
+        if (GROUPED) cand[u] = cand[u] && sgroup[jj] == myg;
+        load_pt<GD>(sorted, jj, rr[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; u++)
+        if (cand[u] && within<METRIC>(q, rr[u], thr)) best = min(best, ld_parent_cached(parent, j0 + u));
+    }
+    return true;
+  });
+  if (best < p) __hip_atomic_store(&parent[p], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
 // Phase 2: flatten the phase-1 forest (no atomics; a racing reader sees an older or a newer ancestor)
 __global__ __launch_bounds__(TPB) void k_flatten0(uint32_t* __restrict__ parent, const uint8_t* __restrict__ flags,
                                                  const uint32_t* __restrict__ cellstart, uint32_t ncells) {
@@ -504,9 +543,11 @@ template <int GD, int METRIC, bool GROUPED>
 __global__ __launch_bounds__(TPB) void k_union(const double* __restrict__ sorted, GridP g, double thr,
                                               const uint32_t* __restrict__ cellstart,
                                               const int32_t* __restrict__ sgroup, const uint8_t* __restrict__ flags,
-                                              uint32_t* __restrict__ parent, int dbg, WorkList wlE) {
+                                              uint32_t* __restrict__ parent, int dbg, WorkList wlE,
+                                              unsigned long long* __restrict__ dbgc) {
   const uint32_t p = wl_fetch(wlE);
   if (p == NONE) return;
+  unsigned c_edge = 0, c_f1 = 0, c_f2 = 0, c_slow = 0, c_link = 0;
   double q[3];
   int cc[3];
   load_pt<GD>(sorted, p, q);
@@ -535,10 +576,19 @@ __global__ __launch_bounds__(TPB) void k_union(const double* __restrict__ sorted
       if (dbg == 1) { rp = min(rp, j); continue; }
       uint32_t pj = ld_parent_cached(parent, j);
       if (dbg == 2) { rp = min(rp, pj); continue; }
-      if (pj == rp) continue;  // already under my root (the common case inside a cluster)
-      uint32_t rj = uf_root(parent, pj);
+      c_edge++;
+      if (pj == rp) { c_f1++; continue; }  // already under my root (the common case inside a cluster)
+      // second hop: j's tree was hooked under my root by an earlier edge (one L2 load instead of two chases)
+      uint32_t pj2 = ld_parent(parent, pj);
+      if (pj2 == rp) {
+        c_f2++;
+        __hip_atomic_store(&parent[j], rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        continue;
+      }
+      c_slow++;
+      uint32_t rj = uf_root(parent, pj2);
       rp = uf_root(parent, rp);
-      if (rj != rp) rp = uf_link(parent, rp, rj);
+      if (rj != rp) { c_link++; rp = uf_link(parent, rp, rj); }
       // compress j's pointer (rp is now an ancestor of j); cached store, same-XCD readers profit
       if (dbg != 3 && pj != rp && j != rp)
         __hip_atomic_store(&parent[j], rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -548,6 +598,13 @@ __global__ __launch_bounds__(TPB) void k_union(const double* __restrict__ sorted
   });
   // one compression store per point (rp is an ancestor of me, so the link stays valid)
   if (rp != me) __hip_atomic_store(&parent[me], rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (dbg == 5) {
+    atomicAdd(&dbgc[0], (unsigned long long)c_edge);
+    atomicAdd(&dbgc[1], (unsigned long long)c_f1);
+    atomicAdd(&dbgc[2], (unsigned long long)c_f2);
+    atomicAdd(&dbgc[3], (unsigned long long)c_slow);
+    atomicAdd(&dbgc[4], (unsigned long long)c_link);
+  }
 }
 
 // flatten + smallest list position per component; lanes of a wave that share a root (the common
@@ -918,9 +975,21 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
     hipLaunchKernelGGL((k_union_init<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup,
                        flags, parent, wlE);
     hipLaunchKernelGGL(k_flatten0, dim3(nb), dim3(TPB), 0, st, parent, flags, cellcnt, g.ncells);
+    const int rounds = getenv("VCP_UNION_ROUNDS") ? atoi(getenv("VCP_UNION_ROUNDS")) : 0;
+    for (int r = 0; r < rounds; r++) {
+      hipLaunchKernelGGL((k_root_hook<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup,
+                         flags, parent, wlE);
+      hipLaunchKernelGGL(k_flatten0, dim3(nb), dim3(TPB), 0, st, parent, flags, cellcnt, g.ncells);
+    }
   }
   hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup, flags,
-                     parent, dbg, wlE);
+                     parent, dbg, wlE, counters + 8);
+  if (dbg == 5) {
+    unsigned long long hd[5];
+    VCP_HIP(ctx, hipMemcpyAsync(hd, counters + 8, sizeof(hd), hipMemcpyDeviceToHost, st));
+    VCP_HIP(ctx, hipStreamSynchronize(st));
+    fprintf(stderr, "[union] edges %llu fast1 %llu fast2 %llu slow %llu links %llu\n", hd[0], hd[1], hd[2], hd[3], hd[4]);
+  }
   vcp_phase(ctx, "flatten_number");
   hipLaunchKernelGGL(k_flatten, dim3(nb), dim3(TPB), 0, st, parent, flags, sord, minord, cellcnt, g.ncells);
   hipLaunchKernelGGL(k_seedflag, dim3(nb), dim3(TPB), 0, st, parent, flags, minord, seedflag, cellcnt, g.ncells);

@@ -111,24 +111,23 @@ def main():
     d_core = torch.zeros(n, dtype=torch.uint8, device=dev)
     d_cls = torch.zeros(n, dtype=torch.uint8, device=dev)
     gathered = torch.zeros(world * n, dtype=torch.int32, device=dev) if world > 1 else None
-    counts = torch.zeros(world, dtype=torch.int64, device=dev) if world > 1 else None
     torch.cuda.synchronize()
 
     phase_ms = {}
 
+    from vtkcloudpoint_amd import distributed as D
+
     def step(record):
-        cf, ev = ctx.dbscan_dev(d_coords.data_ptr(), n, dim, eps, min_pts, metric_id, 0, None,
-                                d_labels.data_ptr(), d_core.data_ptr(), d_cls.data_ptr())
+        if world > 1:
+            # slabs clustered independently, ids made global on the device, int32 labels all-gathered (RCCL)
+            allc, ev = D.slab_cluster(ctx, d_coords, n, dim, eps, min_pts, metric_id, d_labels, gathered)
+            cf = allc
+        else:
+            cf, ev = ctx.dbscan_dev(d_coords.data_ptr(), n, dim, eps, min_pts, metric_id, 0, None,
+                                    d_labels.data_ptr(), d_core.data_ptr(), d_cls.data_ptr())
         if record:
             for name, ms in ctx.timing():
                 phase_ms.setdefault(name, []).append(ms)
-        if world > 1:
-            mine = torch.tensor([cf], dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(counts, mine)
-            off = int(counts[:rank].sum().item())
-            if off:
-                d_labels.add_((d_labels > 0).to(torch.int32) * off)
-            dist.all_gather_into_tensor(gathered, d_labels)
         return cf, ev
 
     for _ in range(args.warmup):
@@ -177,7 +176,7 @@ def main():
                             "monolithic DBImproved.dbscan semantics, metric %s, eps %g, minPts %d%s"
                             % (n, n // 50_000, args.metric, eps, min_pts,
                                "; slabs per rank + RCCL all-gather of int32 labels" if world > 1 else ""),
-                "points_per_gpu": n, "clusters": int(cf), "resident_in_hbm": True,
+                "points_per_gpu": n, "clusters": int(cf.sum().item()) if world > 1 else int(cf), "resident_in_hbm": True,
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

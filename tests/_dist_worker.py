@@ -47,6 +47,28 @@ def main():
     res["offset"] = off
     res["total"] = total
     res["sum"] = D.allreduce_sum_int(rank + 1, "cpu")
+    # 4. slab_cluster (the weak-scaling form bench.py --gpus N runs): oracle-backed stand-in for the context
+    import ctypes as C
+
+    class FakeCtx:
+        def dbscan_dev(self, cptr, n, dim, eps, mp, metric, cf_in, cls, lptr, *a):
+            coords = np.ctypeslib.as_array(C.cast(cptr, C.POINTER(C.c_double)), shape=(n, dim))
+            r = O.dbscan(coords, eps, mp, metric, cf_in)
+            np.ctypeslib.as_array(C.cast(lptr, C.POINTER(C.c_int32)), shape=(n,))[:] = r["labels"]
+            return r["cf"], r["evals"]
+
+    n = 5000
+    slabs = [synth.config_cloud(n, seed=50 + q)["motor"] for q in range(world)]
+    mine = torch.from_numpy(np.ascontiguousarray(slabs[rank]))
+    lab = torch.zeros(n, dtype=torch.int32)
+    gathered = torch.zeros(world * n, dtype=torch.int32)
+    allc, _ = D.slab_cluster(FakeCtx(), mine, n, 2, 0.3, 5, 0, lab, gathered)
+    exp, off = [], 0
+    for q in range(world):
+        r = O.dbscan(slabs[q], 0.3, 5, 0)
+        exp.append(np.where(r["labels"] > 0, r["labels"] + off, 0))
+        off += r["cf"]
+    res["slab_ok"] = bool(np.array_equal(gathered.numpy(), np.concatenate(exp))) and int(allc.sum()) == off
     with open("%s.%d" % (out_path, rank), "w") as f:
         json.dump(res, f)
     dist.barrier()

@@ -98,12 +98,19 @@ def sharded_blocks(backend, motor, eps, min_pts, pts_in_cell, small_max=3, group
 
 def slab_cluster(ctx, d_coords, n, dim, eps, min_pts, metric, d_labels, gathered=None, group=None):
     """Weak-scaling form: cluster this rank's slab (device tensor d_coords [n, dim]), renumber globally,
-    all-gather the labels into `gathered` [world*n] if given.  Returns (global cluster total, evals)."""
+    all-gather the labels into `gathered` [world*n] if given.  The renumbering stays on the device (no host
+    round trip between the clustering and the all-gather).  Returns (per-rank cluster counts tensor, evals)."""
     rank, world = _world(group)
     cf, ev = ctx.dbscan_dev(d_coords.data_ptr(), n, dim, eps, min_pts, metric, 0, None, d_labels.data_ptr())
-    off, total = exclusive_offsets(cf, d_labels.device, group)
-    if off:
-        d_labels.add_((d_labels > 0).to(torch.int32) * off)
-    if world > 1 and gathered is not None:
+    dev = d_labels.device
+    mine = torch.tensor([cf], dtype=torch.int64, device=dev)
+    if world == 1:
+        return mine, ev
+    allc = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allc, mine, group=group)
+    if rank > 0:
+        off = allc[:rank].sum().to(torch.int32)
+        d_labels.add_(torch.where(d_labels > 0, off, torch.zeros((), dtype=torch.int32, device=dev)))
+    if gathered is not None:
         dist.all_gather_into_tensor(gathered, d_labels, group=group)
-    return total, ev
+    return allc, ev

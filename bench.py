@@ -110,17 +110,21 @@ def main():
     d_labels = torch.zeros(n, dtype=torch.int32, device=dev)
     d_core = torch.zeros(n, dtype=torch.uint8, device=dev)
     d_cls = torch.zeros(n, dtype=torch.uint8, device=dev)
-    gathered = torch.zeros(world * n, dtype=torch.int32, device=dev) if world > 1 else None
     torch.cuda.synchronize()
 
     phase_ms = {}
 
     from vtkcloudpoint_amd import distributed as D
+    pipe = None
+    if world > 1:
+        # slabs clustered independently, ids made global on the device, int32 labels all-gathered over RCCL on a
+        # second communicator so that the gather of step k overlaps the clustering of step k+1 (double buffered)
+        big = dist.new_group(backend="nccl")
+        pipe = D.SlabPipeline(ctx, n, dev, depth=2, group=None, big_group=big)
 
     def step(record):
         if world > 1:
-            # slabs clustered independently, ids made global on the device, int32 labels all-gathered (RCCL)
-            allc, ev = D.slab_cluster(ctx, d_coords, n, dim, eps, min_pts, metric_id, d_labels, gathered)
+            allc, ev, _ = pipe.step(d_coords, dim, eps, min_pts, metric_id)
             cf = allc
         else:
             cf, ev = ctx.dbscan_dev(d_coords.data_ptr(), n, dim, eps, min_pts, metric_id, 0, None,
@@ -132,6 +136,8 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
+    if pipe:
+        pipe.flush()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -139,6 +145,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         cf, ev = step(True)
+    if pipe:
+        pipe.flush()  # every step's labels are fully gathered on every rank before the clock stops
     torch.cuda.synchronize()
     if dist:
         dist.barrier()

@@ -69,6 +69,16 @@ def main():
         exp.append(np.where(r["labels"] > 0, r["labels"] + off, 0))
         off += r["cf"]
     res["slab_ok"] = bool(np.array_equal(gathered.numpy(), np.concatenate(exp))) and int(allc.sum()) == off
+    # 5. the pipelined form (async all-gather on a second group, double buffered)
+    big = dist.new_group(backend="gloo")
+    pipe = D.SlabPipeline(FakeCtx(), n, "cpu", depth=2, big_group=big)
+    ok = True
+    for it in range(5):
+        _, _, b = pipe.step(mine, 2, 0.3, 5, 0)
+    pipe.flush()
+    for b in range(2):
+        ok = ok and bool(np.array_equal(pipe.gathered[b].numpy(), np.concatenate(exp)))
+    res["pipe_ok"] = ok
     with open("%s.%d" % (out_path, rank), "w") as f:
         json.dump(res, f)
     dist.barrier()

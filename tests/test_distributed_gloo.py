@@ -25,7 +25,7 @@ def test_sharded_blocks_and_collectives(world, port, tmp_path, oracle):
     res = _run(world, tmp_path, port)
     for r, x in enumerate(res):
         assert x["blocks_labels_equal"] and x["blocks_meta_equal"], (r, x)
-        assert x["varlen_ok"] and x["slab_ok"]
+        assert x["varlen_ok"] and x["slab_ok"] and x["pipe_ok"]
         assert x["offset"] == sum(10 * (q + 1) for q in range(r))
         assert x["total"] == sum(10 * (q + 1) for q in range(world))
         assert x["sum"] == world * (world + 1) // 2

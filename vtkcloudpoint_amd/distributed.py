@@ -114,3 +114,39 @@ def slab_cluster(ctx, d_coords, n, dim, eps, min_pts, metric, d_labels, gathered
     if gathered is not None:
         dist.all_gather_into_tensor(gathered, d_labels, group=group)
     return allc, ev
+
+
+class SlabPipeline:
+    """slab_cluster with the label all-gather of step k overlapped with the clustering of step k+1.
+
+    The big all-gather runs on its own process group (own RCCL communicator and stream) with async_op=True and
+    double-buffered label / gather tensors; the tiny cluster-count gather stays on the default group, so it
+    never queues behind a 40 MB-per-rank transfer.  flush() waits for everything still in flight."""
+
+    def __init__(self, ctx, n, device, depth=2, group=None, big_group=None):
+        self.ctx, self.n, self.depth = ctx, n, depth
+        self.group, self.big_group = group, big_group
+        self.rank, self.world = _world(group)
+        self.labels = [torch.zeros(n, dtype=torch.int32, device=device) for _ in range(depth)]
+        self.gathered = ([torch.zeros(self.world * n, dtype=torch.int32, device=device) for _ in range(depth)]
+                         if self.world > 1 else [None] * depth)
+        self.pending = [None] * depth
+        self.k = 0
+
+    def step(self, d_coords, dim, eps, min_pts, metric):
+        b = self.k % self.depth
+        self.k += 1
+        if self.pending[b] is not None:
+            self.pending[b].wait()  # the buffer pair is free again
+            self.pending[b] = None
+        lab = self.labels[b]
+        allc, ev = slab_cluster(self.ctx, d_coords, self.n, dim, eps, min_pts, metric, lab, None, self.group)
+        if self.world > 1:
+            self.pending[b] = dist.all_gather_into_tensor(self.gathered[b], lab, group=self.big_group, async_op=True)
+        return allc, ev, b
+
+    def flush(self):
+        for b in range(self.depth):
+            if self.pending[b] is not None:
+                self.pending[b].wait()
+                self.pending[b] = None

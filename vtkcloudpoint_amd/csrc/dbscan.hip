@@ -666,24 +666,40 @@ __global__ __launch_bounds__(TPB) void k_flatten(uint32_t* __restrict__ parent, 
   }
 }
 
+// Seeds are marked in a bitmap over list positions (n/32 words); rank(m) = seeds at positions < m comes from
+// a scan over the per-word popcounts, 32x smaller than a scan over n flags.
+__device__ __forceinline__ uint32_t seed_rank(const uint32_t* __restrict__ bits, const uint32_t* __restrict__ pref,
+                                              uint32_t m) {
+  const uint32_t w = m >> 5;
+  return pref[w] + (uint32_t)__popc(bits[w] & ((1u << (m & 31u)) - 1u));
+}
+__global__ __launch_bounds__(TPB) void k_seed_popc(const uint32_t* __restrict__ bits, uint32_t nw, uint32_t* __restrict__ cnt) {
+  uint32_t w = blockIdx.x * TPB + threadIdx.x;
+  if (w < nw) cnt[w] = (uint32_t)__popc(bits[w]);
+}
+
 __global__ __launch_bounds__(TPB) void k_seedflag(const uint32_t* __restrict__ parent, const uint8_t* __restrict__ flags,
                                                  const uint32_t* __restrict__ minord, uint32_t* __restrict__ seedflag,
                                                  const uint32_t* __restrict__ cellstart, uint32_t ncells) {
   const uint32_t nin = cellstart[ncells];
   int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
   if (p >= nin) return;
-  if ((flags[p] & F_EXPAND) && parent[p] == (uint32_t)p) seedflag[minord[p]] = 1u;
+  if ((flags[p] & F_EXPAND) && parent[p] == (uint32_t)p) {
+    const uint32_t m = minord[p];
+    atomicOr(&seedflag[m >> 5], 1u << (m & 31u));
+  }
 }
 
 __global__ __launch_bounds__(TPB) void k_rootk(const uint32_t* __restrict__ parent, const uint8_t* __restrict__ flags,
-                                              const uint32_t* __restrict__ minord, const uint32_t* __restrict__ seedrank,
+                                              const uint32_t* __restrict__ minord, const uint32_t* __restrict__ seedbits,
+                                              const uint32_t* __restrict__ seedpref,
                                               uint32_t* __restrict__ rootk, uint32_t* __restrict__ clseed,
                                               const uint32_t* __restrict__ cellstart, uint32_t ncells) {
   const uint32_t nin = cellstart[ncells];
   int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
   if (p >= nin) return;
   if ((flags[p] & F_EXPAND) && parent[p] == (uint32_t)p) {
-    uint32_t k = seedrank[minord[p]];
+    uint32_t k = seed_rank(seedbits, seedpref, minord[p]);
     rootk[p] = k;
     clseed[k] = minord[p];
   }
@@ -769,7 +785,8 @@ __global__ __launch_bounds__(TPB) void k_output(int64_t n, const uint32_t* __res
                                                const uint32_t* __restrict__ labk,
                                                const uint8_t* __restrict__ in_classed, const int32_t* __restrict__ group,
                                                const uint32_t* __restrict__ groupstart,
-                                               const uint32_t* __restrict__ seedscan, int32_t cf_in,
+                                               const uint32_t* __restrict__ seedbits,
+                                               const uint32_t* __restrict__ seedpref, int32_t cf_in,
                                                int32_t* __restrict__ labels, uint8_t* __restrict__ is_core,
                                                uint8_t* __restrict__ is_classed,
                                                unsigned long long* __restrict__ counters) {
@@ -788,7 +805,7 @@ __global__ __launch_bounds__(TPB) void k_output(int64_t n, const uint32_t* __res
       const bool core = w & 1u, classed = w & 2u;
       int32_t lab = 0;
       if (k1) {
-        uint32_t base = GROUPED ? seedscan[groupstart[group[i]]] : 0u;
+        uint32_t base = GROUPED ? seed_rank(seedbits, seedpref, groupstart[group[i]]) : 0u;
         lab = cf_in + (int32_t)(k1 - base);
       }
       if (lab != 0 || !in_classed) labels[i] = lab;
@@ -814,7 +831,8 @@ __global__ __launch_bounds__(TPB) void k_output(int64_t n, const uint32_t* __res
 
 // per-group statistics: clusters per group and the op counter of the per-block DBImproved instances
 __global__ __launch_bounds__(TPB) void k_group_stats(int32_t G, int glo, int ghi, const uint32_t* __restrict__ groupstart,
-                                                    const uint32_t* __restrict__ seedscan,
+                                                    const uint32_t* __restrict__ seedbits,
+                                                    const uint32_t* __restrict__ seedpref,
                                                     const uint32_t* __restrict__ group_twice,
                                                     uint32_t* __restrict__ group_nclus,
                                                     unsigned long long* __restrict__ evals) {
@@ -825,7 +843,7 @@ __global__ __launch_bounds__(TPB) void k_group_stats(int32_t G, int glo, int ghi
     return;
   }
   unsigned long long ng = groupstart[g + 1] - groupstart[g];
-  unsigned long long kg = seedscan[groupstart[g + 1]] - seedscan[groupstart[g]];
+  unsigned long long kg = seed_rank(seedbits, seedpref, groupstart[g + 1]) - seed_rank(seedbits, seedpref, groupstart[g]);
   if (group_nclus) group_nclus[g] = (uint32_t)kg;
   unsigned long long ev = ng * (ng + kg + group_twice[g]);
   if (ev) atomicAdd(evals, ev);
@@ -953,7 +971,8 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   VCP_TRY(vcp_ensure(ctx, ctx->b_flags, (size_t)n));
   VCP_TRY(vcp_ensure(ctx, ctx->b_parent, (size_t)n * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_minord, (size_t)n * 4));
-  VCP_TRY(vcp_ensure(ctx, ctx->b_seedflag, (size_t)(n + 2) * 4));
+  const uint32_t nw = (uint32_t)(n / 32 + 2);  // bitmap words: positions 0..n (rank(n) = seed total)
+  VCP_TRY(vcp_ensure(ctx, ctx->b_seedflag, ((size_t)nw * 2 + 8) * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_rootcl, (size_t)n * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_clseed, (size_t)n * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_labk, (size_t)n * 4));
@@ -967,7 +986,8 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   uint8_t* flags = ctx->b_flags.as<uint8_t>();
   uint32_t* parent = ctx->b_parent.as<uint32_t>();
   uint32_t* minord = ctx->b_minord.as<uint32_t>();
-  uint32_t* seedflag = ctx->b_seedflag.as<uint32_t>();
+  uint32_t* seedflag = ctx->b_seedflag.as<uint32_t>();  // seed bitmap [nw]
+  uint32_t* seedpref = seedflag + ((nw + 3) & ~3u);      // per-word prefix [nw] (16-B aligned)
   uint32_t* rootk = ctx->b_rootcl.as<uint32_t>();
   uint32_t* clseed = ctx->b_clseed.as<uint32_t>();
   uint32_t* labk = ctx->b_labk.as<uint32_t>();
@@ -1011,7 +1031,7 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   // 6. components of the expanding points
   vcp_phase(ctx, "union");
   hipLaunchKernelGGL(k_init_parent, dim3(nb), dim3(TPB), 0, st, parent, minord, cellcnt, g.ncells);
-  VCP_HIP(ctx, hipMemsetAsync(seedflag, 0, (size_t)(n + 1) * 4, st));
+  VCP_HIP(ctx, hipMemsetAsync(seedflag, 0, (size_t)nw * 4, st));
   VCP_HIP(ctx, hipMemsetAsync(counters, 0, 36 * sizeof(unsigned long long), st));
   const int dbg = getenv("VCP_DBG_UNION") ? atoi(getenv("VCP_DBG_UNION")) : 0;
   // phases 1-2 pay for their extra search pass in 2-D (3 rows); in 3-D (9 rows) they do not
@@ -1037,8 +1057,9 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   vcp_phase(ctx, "flatten_number");
   hipLaunchKernelGGL(k_flatten, dim3(nb), dim3(TPB), 0, st, parent, flags, sord, minord, cellcnt, g.ncells);
   hipLaunchKernelGGL(k_seedflag, dim3(nb), dim3(TPB), 0, st, parent, flags, minord, seedflag, cellcnt, g.ncells);
-  VCP_TRY(vcp_exclusive_scan_u32(ctx, seedflag, seedflag, n + 1, d_total));  // seedflag[n] = total
-  hipLaunchKernelGGL(k_rootk, dim3(nb), dim3(TPB), 0, st, parent, flags, minord, seedflag, rootk, clseed, cellcnt,
+  hipLaunchKernelGGL(k_seed_popc, dim3(vcp_blocks(nw, TPB)), dim3(TPB), 0, st, seedflag, nw, seedpref);
+  VCP_TRY(vcp_exclusive_scan_u32(ctx, seedpref, seedpref, nw, d_total));
+  hipLaunchKernelGGL(k_rootk, dim3(nb), dim3(TPB), 0, st, parent, flags, minord, seedflag, seedpref, rootk, clseed, cellcnt,
                      g.ncells);
 
   // 7. border rule, then outputs in caller order
@@ -1049,10 +1070,10 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
                      parent, sord, rootk, clseed, labk, counters, GROUPED ? ext->d_group_twice : nullptr, wlB);
   vcp_phase(ctx, "output");
   hipLaunchKernelGGL((k_output<GROUPED>), dim3(nb), dim3(TPB), 0, st, n, pos, labk, d_in_classed, d_group,
-                     GROUPED ? ext->d_groupstart : nullptr, seedflag, cf_in, d_labels, d_is_core, d_is_classed, counters);
+                     GROUPED ? ext->d_groupstart : nullptr, seedflag, seedpref, cf_in, d_labels, d_is_core, d_is_classed, counters);
   if (GROUPED) {
     hipLaunchKernelGGL(k_group_stats, dim3(vcp_blocks(G, TPB)), dim3(TPB), 0, st, G, glo, ghi, ext->d_groupstart,
-                       seedflag, ext->d_group_twice, ext->d_group_nclus, counters + 3);
+                       seedflag, seedpref, ext->d_group_twice, ext->d_group_nclus, counters + 3);
     if (ext->d_group_evals)
       VCP_HIP(ctx, hipMemcpyAsync(ext->d_group_evals, counters + 3, 8, hipMemcpyDeviceToDevice, st));
   }

@@ -1,9 +1,5 @@
 // vcp_ctx.hip -- context lifetime, workspace, per-phase hipEvent timing and the u32 scan used
 // by the grid build and the canonical cluster numbering.
-#include <string.h>  // rocprim's texture_cache_iterator.hpp calls ::memset without including it
-
-#include <rocprim/rocprim.hpp>
-
 #include <cstring>
 
 #include "vcp_ctx.hpp"
@@ -78,13 +74,111 @@ int vcp_phase_finish(vcp_ctx* ctx) {
 }
 
 // ------------------------------------------------------------------------------------------
-// exclusive scan (u32): rocPRIM's single-pass decoupled look-back scan (a plain library primitive); the
-// grand total, when asked for, is out[n-1] + in[n-1] (the last input is saved first: in-place is allowed)
+// exclusive scan (u32), reduce-then-scan over tiles of 8192 elements:
+//   k_scan_tile_sums  one workgroup per tile, 16-B loads, tile sum
+//   k_scan_offsets    one workgroup scans the tile sums (and emits the grand total)
+//   k_scan_tiles      one workgroup per tile re-reads it, scans it in 8 chunks of 1024 with a running carry
+// 2 reads + 1 write of the array; in-place allowed (a tile is read before it is written, tiles are disjoint).
 // ------------------------------------------------------------------------------------------
 namespace {
-__global__ void k_scan_total(const uint32_t* __restrict__ out_last, const uint32_t* __restrict__ in_last,
-                             uint32_t* __restrict__ total) {
-  *total = *out_last + *in_last;
+constexpr int ST = 256;            // threads
+constexpr int SCH = 8;             // chunks per tile
+constexpr int STILE = ST * 4 * SCH;  // 8192 elements per tile
+
+__device__ __forceinline__ uint32_t wave_incl(uint32_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// block-wide exclusive scan of one value per thread; *total = block sum.  Two barriers.
+__device__ __forceinline__ uint32_t block_excl(uint32_t v, uint32_t* total, uint32_t* sm /*[ST/64 + 1]*/) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t inc = wave_incl(v, lane);
+  if (lane == 63) sm[w] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < ST / 64; k++) {
+    const uint32_t x = sm[k];
+    if (k < w) base += x;
+    tot += x;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+template <bool VEC>
+__device__ __forceinline__ uint4 ld4(const uint32_t* __restrict__ in, int64_t i, int64_t n) {
+  if (VEC && i + 3 < n) return *reinterpret_cast<const uint4*>(in + i);
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (i < n) v.x = in[i];
+  if (i + 1 < n) v.y = in[i + 1];
+  if (i + 2 < n) v.z = in[i + 2];
+  if (i + 3 < n) v.w = in[i + 3];
+  return v;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(ST) void k_scan_tile_sums(const uint32_t* __restrict__ in, int64_t n,
+                                                      uint32_t* __restrict__ tsum) {
+  const int64_t base = (int64_t)blockIdx.x * STILE;
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < SCH; k++) {
+    const uint4 v = ld4<VEC>(in, base + ((int64_t)k * ST + threadIdx.x) * 4, n);
+    s += v.x + v.y + v.z + v.w;
+  }
+  __shared__ uint32_t sm[ST / 64 + 1];
+  uint32_t tot;
+  block_excl(s, &tot, sm);
+  if (threadIdx.x == 0) tsum[blockIdx.x] = tot;
+}
+
+// single workgroup: exclusive scan of nt tile sums in place; thread t owns a contiguous run
+__global__ __launch_bounds__(ST) void k_scan_offsets(uint32_t* __restrict__ tsum, int nt, uint32_t* __restrict__ total) {
+  const int per = (nt + ST - 1) / ST;
+  const int lo = min((int)threadIdx.x * per, nt), hi = min(lo + per, nt);
+  uint32_t s = 0;
+  for (int i = lo; i < hi; i++) s += tsum[i];
+  __shared__ uint32_t sm[ST / 64 + 1];
+  uint32_t tot;
+  uint32_t pre = block_excl(s, &tot, sm);
+  for (int i = lo; i < hi; i++) {
+    const uint32_t v = tsum[i];
+    tsum[i] = pre;
+    pre += v;
+  }
+  if (threadIdx.x == 0 && total) *total = tot;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(ST) void k_scan_tiles(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int64_t n,
+                                                  const uint32_t* __restrict__ toff) {
+  const int64_t base = (int64_t)blockIdx.x * STILE;
+  __shared__ uint32_t sm[ST / 64 + 1];
+  uint32_t carry = toff[blockIdx.x];
+#pragma unroll 1
+  for (int k = 0; k < SCH; k++) {
+    const int64_t i = base + ((int64_t)k * ST + threadIdx.x) * 4;
+    const uint4 v = ld4<VEC>(in, i, n);
+    uint32_t tot;
+    const uint32_t pre = carry + block_excl(v.x + v.y + v.z + v.w, &tot, sm);
+    const uint4 o = make_uint4(pre, pre + v.x, pre + v.x + v.y, pre + v.x + v.y + v.z);
+    if (VEC && i + 3 < n) {
+      *reinterpret_cast<uint4*>(out + i) = o;
+    } else {
+      if (i < n) out[i] = o.x;
+      if (i + 1 < n) out[i + 1] = o.y;
+      if (i + 2 < n) out[i + 2] = o.z;
+      if (i + 3 < n) out[i + 3] = o.w;
+    }
+    carry += tot;
+  }
 }
 }  // namespace
 
@@ -94,15 +188,16 @@ int vcp_exclusive_scan_u32(vcp_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, 
     if (d_total) VCP_HIP(ctx, hipMemsetAsync(d_total, 0, 4, ctx->stream));
     return VCP_OK;
   }
-  size_t tb = 0;
-  VCP_HIP(ctx, rocprim::exclusive_scan(nullptr, tb, d_in, d_out, 0u, (size_t)n, rocprim::plus<uint32_t>(), ctx->stream));
-  VCP_TRY(vcp_ensure(ctx, ctx->b_scan_tmp, tb + 64));
-  uint32_t* saved = reinterpret_cast<uint32_t*>(ctx->b_scan_tmp.as<char>() + ((tb + 15) & ~(size_t)15));
-  if (d_total)
-    VCP_HIP(ctx, hipMemcpyAsync(saved, d_in + (n - 1), 4, hipMemcpyDeviceToDevice, ctx->stream));
-  VCP_HIP(ctx, rocprim::exclusive_scan(ctx->b_scan_tmp.p, tb, d_in, d_out, 0u, (size_t)n, rocprim::plus<uint32_t>(),
-                                       ctx->stream));
-  if (d_total) hipLaunchKernelGGL(k_scan_total, dim3(1), dim3(1), 0, ctx->stream, d_out + (n - 1), saved, d_total);
+  const int64_t nt = (n + STILE - 1) / STILE;
+  VCP_TRY(vcp_ensure(ctx, ctx->b_scan_tmp, (size_t)(nt + 16) * sizeof(uint32_t)));
+  uint32_t* tsum = ctx->b_scan_tmp.as<uint32_t>();
+  const bool vec = (((uintptr_t)d_in | (uintptr_t)d_out) & 15u) == 0;
+  hipStream_t st = ctx->stream;
+  if (vec) hipLaunchKernelGGL(k_scan_tile_sums<true>, dim3((unsigned)nt), dim3(ST), 0, st, d_in, n, tsum);
+  else hipLaunchKernelGGL(k_scan_tile_sums<false>, dim3((unsigned)nt), dim3(ST), 0, st, d_in, n, tsum);
+  hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(ST), 0, st, tsum, (int)nt, d_total);
+  if (vec) hipLaunchKernelGGL(k_scan_tiles<true>, dim3((unsigned)nt), dim3(ST), 0, st, d_in, d_out, n, tsum);
+  else hipLaunchKernelGGL(k_scan_tiles<false>, dim3((unsigned)nt), dim3(ST), 0, st, d_in, d_out, n, tsum);
   VCP_HIP(ctx, hipGetLastError());
   return VCP_OK;
 }

@@ -182,6 +182,17 @@ int vcp_icp_dev(vcp_ctx* ctx, const double* d_model, int64_t nm, const double* d
 int vcp_icp_sums(vcp_ctx* ctx, const double* model, int64_t nm, const double* data, int64_t nd,
                  const double R[9], const double T[3], double sums[16], int32_t* nn);
 
+/* -- minimal bounding circles ---------------------------------------------
+ * Replaces Tools.getCircles (BC/Tools.cs:394-409) / Geometry.FindMinimalBoundingCircle
+ * (BC/Geometry.cs:247-319; gift-wrap hull :122-208, circle through 2 or 3 hull points :260-312): for
+ * every cluster 1..K with more than 3 points the smallest enclosing circle of its (x,y).
+ * xy [n*2] = (X,Y) for the 3-D view or (motor_x,motor_y) for the 2-D one; labels [n]; order [m] = the
+ * list order the C# iterates (clusForMerge; NULL = 0..n-1, then m must equal n): "first in the list"
+ * decides every tie.  centers [K*2], radius [K], valid [K] (0 = cluster skipped), hull_n [K] may be NULL.
+ * Bit-identical to the C# arithmetic (binary64, no FMA contraction). */
+int vcp_mcc(vcp_ctx* ctx, const double* xy, const int32_t* labels, const int64_t* order, int64_t m,
+            int64_t n, int32_t K, double* centers, double* radius, uint8_t* valid, int32_t* hull_n);
+
 /* -- matching ------------------------------------------------------------------------------
  * Replaces MainForm.calMatchedCoords (FrmMain.cs:3572-3587) + RecorrectMatchingPtsByDistance
  * (:3588-3618, getDisP :829-835): matched = M * (c,1); nearest truth by Euclidean distance

@@ -227,6 +227,32 @@ def icp(model, data, tol=1e-4, max_iter=100, stop_rule=STOP_SSE_DELTA):
     return dict(R=R.reshape(3, 3), T=T, sse=sse.value, rmse=rmse.value, iters=it.value)
 
 
+def min_circle(pts):
+    pts = _f64(pts, 2)
+    c = np.zeros(2)
+    r = C.c_double(0)
+    hn = C.c_int32(0)
+    hull = np.zeros((len(pts), 2))
+    _chk(lib().orc_min_circle(_p(pts, C.c_double), C.c_int64(len(pts)), _p(c, C.c_double), C.byref(r),
+                              _p(hull, C.c_double), C.c_int64(len(pts)), C.byref(hn)))
+    return c, r.value, hull[: hn.value]
+
+
+def get_circles(xy, labels, K, order=None):
+    xy = _f64(xy, 2)
+    labels = np.ascontiguousarray(labels, np.int32)
+    order = None if order is None else np.ascontiguousarray(order, np.int64)
+    m = len(labels) if order is None else len(order)
+    centers = np.zeros((K, 2))
+    radius = np.zeros(K)
+    valid = np.zeros(K, np.uint8)
+    hn = np.zeros(K, np.int32)
+    _chk(lib().orc_get_circles(_p(xy, C.c_double), _p(labels, C.c_int32), _p(order, C.c_int64), C.c_int64(m),
+                               C.c_int32(K), _p(centers, C.c_double), _p(radius, C.c_double), _p(valid, C.c_uint8),
+                               _p(hn, C.c_int32)))
+    return dict(centers=centers, radius=radius, valid=valid, hull_n=hn)
+
+
 def match(centers, truths, M, max_dist):
     centers = _f64(centers, 3)
     truths = _f64(truths, 3)

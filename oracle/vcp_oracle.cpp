@@ -1021,6 +1021,156 @@ int orc_icp(const double* model, int64_t nm, const double* data, int64_t nd, dou
   return ORC_OK;
 }
 
+// -------------------------------------------------------------------------------------
+// Minimal bounding circle of a cluster: Geometry.FindMinimalBoundingCircle,
+// BC/Geometry.cs:247-319, with MakeConvexHull :122-208, AngleValue :220-246, CircleEnclosesPoints :322-337,
+// FindCircle :340-372, FindIntersection :373-432, line by line.  HullCull (:83-120) culls nothing: the
+// Rectangle2D it tests against never gets Left/Right/Top/Bottom set (BC/DataModel.cs:191-208), so they are 0
+// and the "outside the box" test is always true; only NaN coordinates would be dropped.
+namespace {
+double AngleValue(double x1, double y1, double x2, double y2) {
+  double dx = x2 - x1, ax = std::fabs(dx), dy = y2 - y1, ay = std::fabs(dy), t;
+  if (ax + ay == 0)
+    t = 40.0;  // 360f / 9f
+  else
+    t = dy / (ax + ay);
+  if (dx < 0)
+    t = 2 - t;
+  else if (dy < 0)
+    t = 4 + t;
+  return t * 90;
+}
+struct P2 {
+  double x, y;
+};
+bool CircleEnclosesPoints(P2 c, double radius2, const std::vector<P2>& pts, int s1, int s2, int s3) {
+  for (int i = 0; i < (int)pts.size(); i++)
+    if (i != s1 && i != s2 && i != s3) {
+      double dx = c.x - pts[i].x, dy = c.y - pts[i].y;
+      if (dx * dx + dy * dy > radius2) return false;
+    }
+  return true;
+}
+void FindCircle(P2 a, P2 b, P2 c, P2* center, double* radius2) {
+  double x1 = (b.x + a.x) / 2, y1 = (b.y + a.y) / 2, dy1 = b.x - a.x, dx1 = -(b.y - a.y);
+  double x2 = (c.x + b.x) / 2, y2 = (c.y + b.y) / 2, dy2 = c.x - b.x, dx2 = -(c.y - b.y);
+  // FindIntersection(p1=(x1,y1), p2=(x1+dx1,y1+dy1), p3=(x2,y2), p4=(x2+dx2,y2+dy2))
+  P2 p1{x1, y1}, p2{x1 + dx1, y1 + dy1}, p3{x2, y2}, p4{x2 + dx2, y2 + dy2};
+  double dx12 = p2.x - p1.x, dy12 = p2.y - p1.y, dx34 = p4.x - p3.x, dy34 = p4.y - p3.y;
+  double denominator = (dy12 * dx34 - dx12 * dy34);
+  double t1 = ((p1.x - p3.x) * dy34 + (p3.y - p1.y) * dx34) / denominator;  // double division never throws
+  center->x = p1.x + dx12 * t1;
+  center->y = p1.y + dy12 * t1;
+  double dx = center->x - a.x, dy = center->y - a.y;
+  *radius2 = dx * dx + dy * dy;
+}
+}  // namespace
+
+int orc_min_circle(const double* pts, int64_t cnt, double center[2], double* radius, double* hull_xy,
+                   int64_t hull_cap, int32_t* hull_n) {
+  if (cnt <= 0) return ORC_ERR_EMPTY;  // points[0]
+  // HullCull: keeps every point whose coordinates are not NaN (x <= 0 || x >= 0 || ...)
+  std::vector<int64_t> rem;
+  for (int64_t i = 0; i < cnt; i++) {
+    double x = pts[2 * i], y = pts[2 * i + 1];
+    if (x <= 0 || x >= 0 || y <= 0 || y >= 0) rem.push_back(i);
+  }
+  if (rem.empty()) return ORC_ERR_EMPTY;
+  // :129-150 smallest Y, then smallest X (first wins exact ties)
+  size_t bi = 0;
+  for (size_t k = 0; k < rem.size(); k++) {
+    double y = pts[2 * rem[k] + 1], x = pts[2 * rem[k]];
+    double by = pts[2 * rem[bi] + 1], bx = pts[2 * rem[bi]];
+    if (y < by || (y == by && x < bx)) bi = k;
+  }
+  std::vector<P2> hull;
+  hull.push_back(P2{pts[2 * rem[bi]], pts[2 * rem[bi] + 1]});
+  rem.erase(rem.begin() + bi);
+  double sweep_angle = 0;
+  while (!rem.empty()) {  // the C# indexes points[0] at :168 and would throw on an empty list
+    double X = hull.back().x, Y = hull.back().y;
+    size_t best = 0;
+    double best_angle = 3600;
+    for (size_t k = 0; k < rem.size(); k++) {
+      double ta = AngleValue(X, Y, pts[2 * rem[k]], pts[2 * rem[k] + 1]);
+      if (ta >= sweep_angle && best_angle > ta) {
+        best_angle = ta;
+        best = k;
+      }
+    }
+    double first_angle = AngleValue(X, Y, hull[0].x, hull[0].y);
+    if (first_angle >= sweep_angle && best_angle >= first_angle) break;
+    hull.push_back(P2{pts[2 * rem[best]], pts[2 * rem[best] + 1]});
+    rem.erase(rem.begin() + best);
+    sweep_angle = best_angle;
+  }
+  if (hull_n) *hull_n = (int32_t)hull.size();
+  if (hull_xy)
+    for (size_t k = 0; k < hull.size() && (int64_t)k < hull_cap; k++) {
+      hull_xy[2 * k] = hull[k].x;
+      hull_xy[2 * k + 1] = hull[k].y;
+    }
+  // :252-312
+  P2 best_center{pts[0], pts[1]};
+  double best_radius2 = std::numeric_limits<double>::max();
+  const int h = (int)hull.size();
+  for (int i = 0; i < h - 1; i++)
+    for (int j = i + 1; j < h; j++) {
+      P2 tc{(hull[i].x + hull[j].x) / 2.0, (hull[i].y + hull[j].y) / 2.0};
+      double dx = tc.x - hull[i].x, dy = tc.y - hull[i].y;
+      double tr2 = dx * dx + dy * dy;
+      if (tr2 < best_radius2 && CircleEnclosesPoints(tc, tr2, hull, i, j, -1)) {
+        best_center = tc;
+        best_radius2 = tr2;
+      }
+    }
+  for (int i = 0; i < h - 2; i++)
+    for (int j = i + 1; j < h - 1; j++)
+      for (int k = j + 1; k < h; k++) {
+        P2 tc;
+        double tr2;
+        FindCircle(hull[i], hull[j], hull[k], &tc, &tr2);
+        if (tr2 < best_radius2 && CircleEnclosesPoints(tc, tr2, hull, i, j, k)) {
+          best_center = tc;
+          best_radius2 = tr2;
+        }
+      }
+  center[0] = best_center.x;
+  center[1] = best_center.y;
+  *radius = best_radius2 == std::numeric_limits<double>::max() ? 0.0 : std::sqrt(best_radius2);
+  return ORC_OK;
+}
+
+// Tools.getCircles (BC/Tools.cs:394-409): one circle per cluster with more than 3 points.
+int orc_get_circles(const double* xy, const int32_t* labels, const int64_t* order, int64_t m, int32_t K,
+                    double* centers, double* radius, uint8_t* valid, int32_t* hull_n) {
+  if (m < 0 || K < 0) return ORC_ERR_ARG;
+  std::vector<std::vector<double>> li(K);
+  for (int64_t t = 0; t < m; t++) {
+    int64_t i = order ? order[t] : t;
+    int32_t id = labels[i];
+    if (id != 0) {
+      if (id < 1 || id > K) return ORC_ERR_INDEX;
+      li[id - 1].push_back(xy[2 * i]);
+      li[id - 1].push_back(xy[2 * i + 1]);
+    }
+  }
+  for (int32_t k = 0; k < K; k++) {
+    valid[k] = 0;
+    radius[k] = 0;
+    centers[2 * k] = centers[2 * k + 1] = 0;
+    if (hull_n) hull_n[k] = 0;
+    int64_t cnt = (int64_t)li[k].size() / 2;
+    if (cnt <= 3) continue;  // :400
+    int32_t hn = 0;
+    int rc = orc_min_circle(li[k].data(), cnt, centers + 2 * k, radius + k, nullptr, 0, &hn);
+    if (rc) return rc;
+    valid[k] = 1;
+    if (hull_n) hull_n[k] = hn;
+  }
+  return ORC_OK;
+}
+
 int orc_match(const double* centers, int32_t K, const double* truths, int32_t T, const double M[16],
               double max_dist, double* mxyz, uint8_t* is_matched, int32_t* nearest, double* nearest_dist,
               int32_t* count_matched) {

@@ -139,6 +139,14 @@ int orc_icp(const double* model, int64_t nm, const double* data, int64_t nd, dou
             int max_iter, int stop_rule, double R[9], double T[3], double* sse, double* rmse,
             int32_t* iters);
 
+/* Geometry.FindMinimalBoundingCircle (BC/Geometry.cs:247-319) on `cnt` points (x,y) in list order: gift-wrap
+ * hull, then the smallest enclosing circle through 2 or 3 hull points, first found on ties.  hull_xy may be NULL. */
+int orc_min_circle(const double* pts, int64_t cnt, double center[2], double* radius, double* hull_xy,
+                   int64_t hull_cap, int32_t* hull_n);
+/* Tools.getCircles (BC/Tools.cs:394-409): a circle for every cluster 1..K with more than 3 points (valid[k]). */
+int orc_get_circles(const double* xy, const int32_t* labels, const int64_t* order, int64_t m, int32_t K,
+                    double* centers, double* radius, uint8_t* valid, int32_t* hull_n);
+
 /* calMatchedCoords + RecorrectMatchingPtsByDistance (FrmMain.cs:3572-3618, :829-835). */
 int orc_match(const double* centers, int32_t K, const double* truths, int32_t T,
               const double M[16], double max_dist, double* matched_xyz, uint8_t* is_matched,

@@ -105,3 +105,50 @@ def test_centroids_merge_refresh(oracle):
     lab, nk, r3, r2, rc = oracle.refresh_by_dictionary(xyz, motor, labels, 5, map_to)
     assert nk == 3 and lab.tolist() == [1, 1, 2, 1, 3, 1, 1, 2, 1, 3] and rc.tolist() == [6, 2, 2]
     assert np.allclose(r3[0], xyz[[0, 5, 1, 6, 3, 8]].mean(0))
+
+
+def test_minimal_bounding_circle_oracle(oracle):
+    """Geometry.FindMinimalBoundingCircle literal port: hand cases + Welzl's algorithm as an independent check."""
+    c, r, hull = oracle.min_circle(np.array([[0, 0], [2, 0], [2, 2], [0, 2], [1, 1], [0.5, 1.5]], float))
+    assert c.tolist() == [1.0, 1.0] and r == np.sqrt(2.0) and hull.tolist() == [[0, 0], [2, 0], [2, 2], [0, 2]]
+    c, r, hull = oracle.min_circle(np.array([[0, 0], [4, 0], [1, 0.5], [2, 0.2]], float))
+    assert c.tolist() == [2.0, 0.0] and r == 2.0  # obtuse: the circle on the longest side
+
+    def welzl(P):
+        P = [tuple(p) for p in P]
+
+        def c2(a, b):
+            c = ((a[0] + b[0]) / 2, (a[1] + b[1]) / 2)
+            return c, np.hypot(a[0] - c[0], a[1] - c[1])
+
+        def c3(a, b, c):
+            d = 2 * (a[0] * (b[1] - c[1]) + b[0] * (c[1] - a[1]) + c[0] * (a[1] - b[1]))
+            if d == 0:
+                return None
+            ux = ((a[0] ** 2 + a[1] ** 2) * (b[1] - c[1]) + (b[0] ** 2 + b[1] ** 2) * (c[1] - a[1]) + (c[0] ** 2 + c[1] ** 2) * (a[1] - b[1])) / d
+            uy = ((a[0] ** 2 + a[1] ** 2) * (c[0] - b[0]) + (b[0] ** 2 + b[1] ** 2) * (a[0] - c[0]) + (c[0] ** 2 + c[1] ** 2) * (b[0] - a[0])) / d
+            return (ux, uy), np.hypot(a[0] - ux, a[1] - uy)
+
+        def inside(c, p):
+            return np.hypot(p[0] - c[0][0], p[1] - c[0][1]) <= c[1] * (1 + 1e-12)
+
+        c = None
+        for i, p in enumerate(P):
+            if c is None or not inside(c, p):
+                c = (p, 0.0)
+                for j, q in enumerate(P[:i]):
+                    if not inside(c, q):
+                        c = c2(p, q)
+                        for s in P[:j]:
+                            if not inside(c, s):
+                                c = c3(p, q, s) or c
+        return c
+
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        P = rng.standard_normal((200, 2))
+        c, r, hull = oracle.min_circle(P)
+        assert abs(r - welzl(P)[1]) < 1e-9
+    # Tools.getCircles skips clusters of <= 3 points
+    g = oracle.get_circles(np.zeros((3, 2)), np.array([1, 1, 1], np.int32), 1)
+    assert g["valid"].tolist() == [0]

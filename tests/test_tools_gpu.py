@@ -85,3 +85,28 @@ def test_match(vcp_ctx, oracle):
     with pytest.raises(N.VcpError) as e:
         vcp_ctx.match(centers, np.zeros((0, 3)), M, 5.0)
     assert e.value.code == -2
+
+
+def test_minimal_bounding_circles(vcp_ctx, oracle):
+    """Tools.getCircles / Geometry.FindMinimalBoundingCircle: bit-exact vs the literal port."""
+    # hand-checkable: the circumcircle of a square, and an obtuse triangle (circle on the longest side)
+    xy = np.array([[0, 0], [2, 0], [2, 2], [0, 2], [1, 1], [0.5, 1.5], [10, 10], [14, 10], [11, 10.5], [12, 10.2]], float)
+    lab = np.array([1, 1, 1, 1, 1, 1, 2, 2, 2, 2], np.int32)
+    g = vcp_ctx.mcc(xy, lab, 2)
+    assert g["valid"].tolist() == [1, 1] and np.allclose(g["centers"], [[1, 1], [12, 10]])
+    assert np.allclose(g["radius"], [np.sqrt(2), 2.0]) and g["hull_n"][0] == 4
+    for d in (synth.config_c1(), synth.config_cloud(300_000, seed=23)):
+        o = oracle.block_pipeline(d["motor"], 0.1 if len(d["motor"]) > 20000 else 0.3, 10 if len(d["motor"]) > 20000 else 5, 200, 3)
+        K = o["cluster_amount"]
+        for coords in (d["motor"], d["xyz"][:, :2].copy()):  # the 2-D and the 3-D view (Tools.cs:394, is3D)
+            ref = oracle.get_circles(coords, o["labels"], K, o["order"])
+            got = vcp_ctx.mcc(coords, o["labels"], K, o["order"])
+            assert np.array_equal(ref["valid"], got["valid"]) and np.array_equal(ref["hull_n"], got["hull_n"])
+            assert np.array_equal(ref["centers"], got["centers"]) and np.array_equal(ref["radius"], got["radius"])
+            assert ref["valid"].sum() > 0
+    # clusters of <= 3 points are skipped (Tools.cs:400); labels beyond K index clusList out of range
+    g = vcp_ctx.mcc(xy[:3], np.array([1, 1, 1], np.int32), 1)
+    assert g["valid"].tolist() == [0]
+    with pytest.raises(N.VcpError) as e:
+        vcp_ctx.mcc(xy, lab + 5, 2)
+    assert e.value.code == -4

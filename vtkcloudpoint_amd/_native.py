@@ -24,7 +24,7 @@ SYMBOLS = [
     "vcp_dbscan", "vcp_dbscan_dev", "vcp_dbscan_blocks", "vcp_blocks_begin", "vcp_blocks_begin_dev",
     "vcp_blocks_share", "vcp_blocks_cluster_dev", "vcp_blocks_finish_dev", "vcp_centroids", "vcp_centroids_dev",
     "vcp_merge_centroids", "vcp_refresh_by_dictionary", "vcp_icp", "vcp_icp_dev", "vcp_icp_sums",
-    "vcp_match",
+    "vcp_match", "vcp_mcc",
 ]
 
 
@@ -290,3 +290,18 @@ class Context:
                                               _ptr(d_block_of), _ptr(d_merge_order), C.byref(m), C.byref(kept),
                                               C.byref(dels), C.byref(ca), C.byref(ev)))
         return dict(m=m.value, kept=kept.value, del_sum=dels.value, cluster_amount=ca.value, evals=ev.value)
+
+    def mcc(self, xy, labels, K, order=None):
+        """Tools.getCircles: minimal bounding circle of every cluster with more than 3 points."""
+        xy = _f64(xy, 2)
+        labels = np.ascontiguousarray(labels, np.int32)
+        order = None if order is None else np.ascontiguousarray(order, np.int64)
+        n = len(labels)
+        m = n if order is None else len(order)
+        centers = np.zeros((K, 2))
+        radius = np.zeros(K)
+        valid = np.zeros(K, np.uint8)
+        hn = np.zeros(K, np.int32)
+        self._chk(lib().vcp_mcc(self._h, _ptr(xy), _ptr(labels), _ptr(order), C.c_int64(m), C.c_int64(n), C.c_int32(K),
+                                _ptr(centers), _ptr(radius), _ptr(valid), _ptr(hn)))
+        return dict(centers=centers, radius=radius, valid=valid, hull_n=hn)

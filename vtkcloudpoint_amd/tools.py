@@ -106,6 +106,41 @@ class Tools:
             centers2D.append(Point3D(c2[k, 0], c2[k, 1], 0, ob.clusId, True))
 
 
+class Point2D:
+    """BaseClass/DataModel.cs:66-98."""
+
+    def __init__(self, xx, yy, cluID=0):
+        self.x, self.y, self.clusID = float(xx), float(yy), int(cluID)
+        self.isFilter = False
+        self.radius = 0.0
+
+
+def getCircles(clusList, is3D, ctx=None):
+    """Tools.getCircles (BaseClass/Tools.cs:394-409): one Point2D (centre, radius, clusID = position+1) per
+    cluster with more than 3 points; Geometry.FindMinimalBoundingCircle runs on the GPU (vcp_mcc)."""
+    ctx = ctx or default_context()
+    K = len(clusList)
+    pts, lab = [], []
+    for j, ob in enumerate(clusList):
+        for p in ob.li:
+            pts.append((p.X, p.Y) if is3D else (p.motor_x, p.motor_y))
+            lab.append(j + 1)
+    if K == 0 or not pts:
+        return []
+    r = ctx.mcc(np.array(pts, np.float64), np.array(lab, np.int32), K)
+    circles = []
+    for j in range(K):
+        if not r["valid"][j]:
+            continue
+        c = Point2D(r["centers"][j, 0], r["centers"][j, 1], j + 1)
+        c.radius = float(r["radius"][j])
+        circles.append(c)
+    return circles
+
+
+Tools.getCircles = staticmethod(getCircles)
+
+
 class ClusterPipeline:
     """The MainForm state and methods on the path: getClusterFromMotor + DoWork3/StartCode + CompleteWork3
     (FrmMain.cs:1214-1291, :1340-1361, :2782-2794, :1432-1544) as one blocking call."""

@@ -201,6 +201,14 @@ int vcp_match(vcp_ctx* ctx, const double* centers, int32_t K, const double* trut
               const double M[16], double max_dist, double* matched_xyz, uint8_t* is_matched,
               int32_t* nearest, double* nearest_dist, int32_t* count_matched);
 
+/* -- truth-guided assignment -------------------------------------------------
+ * Replaces the query of MainForm.refreshClusList (FrmMain.cs:3437-3467): per raw point (motor_x, motor_y)
+ * the nearest truth (tmp_X, tmp_Y) with Euclidean distance < radius; among equal distances the LAST truth
+ * in list order wins (OrderByDescending(DISTANCE).Reverse()); ids[i] = that truth's clusterId, 0 = none;
+ * *outliers = number of points with id 0 ("yedian"). */
+int vcp_assign_truths(vcp_ctx* ctx, const double* motor, int64_t n, const double* truths_xy,
+                      const int32_t* truth_ids, int32_t T, double radius, int32_t* ids, int64_t* outliers);
+
 #ifdef __cplusplus
 }
 #endif

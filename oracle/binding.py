@@ -253,6 +253,18 @@ def get_circles(xy, labels, K, order=None):
     return dict(centers=centers, radius=radius, valid=valid, hull_n=hn)
 
 
+def assign_truths(motor, truths_xy, truth_ids, radius):
+    motor = _f64(motor, 2)
+    truths_xy = _f64(truths_xy, 2)
+    truth_ids = np.ascontiguousarray(truth_ids, np.int32)
+    ids = np.zeros(len(motor), np.int32)
+    out = C.c_int64(0)
+    _chk(lib().orc_assign_truths(_p(motor, C.c_double), C.c_int64(len(motor)), _p(truths_xy, C.c_double),
+                                 _p(truth_ids, C.c_int32), C.c_int32(len(truth_ids)), C.c_double(radius),
+                                 _p(ids, C.c_int32), C.byref(out)))
+    return ids, out.value
+
+
 def match(centers, truths, M, max_dist):
     centers = _f64(centers, 3)
     truths = _f64(truths, 3)

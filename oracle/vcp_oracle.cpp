@@ -1171,6 +1171,33 @@ int orc_get_circles(const double* xy, const int32_t* labels, const int64_t* orde
   return ORC_OK;
 }
 
+// MainForm.refreshClusList (FrmMain.cs:3437-3467): per raw point the nearest truth point
+// with sqrt((tmp_X - motor_x)^2 + (tmp_Y - motor_y)^2) < radius; OrderByDescending(DISTANCE).Reverse() makes the
+// LAST truth in list order win among equal distances; id = that truth's clusterId, 0 = none ("yedian").
+int orc_assign_truths(const double* motor, int64_t n, const double* truths_xy, const int32_t* truth_ids, int32_t T,
+                      double radius, int32_t* ids, int64_t* outliers) {
+  if (n < 0 || T < 0) return ORC_ERR_ARG;
+  int64_t out = 0;
+  for (int64_t i = 0; i < n; i++) {
+    int32_t id = 0;
+    double best = 0;
+    bool have = false;
+    for (int32_t s = 0; s < T; s++) {
+      double ax = truths_xy[2 * s] - motor[2 * i], ay = truths_xy[2 * s + 1] - motor[2 * i + 1];
+      double d = std::sqrt(ax * ax + ay * ay);
+      if (d < radius && (!have || d <= best)) {  // <= : later entries replace equal ones
+        best = d;
+        id = truth_ids[s];
+        have = true;
+      }
+    }
+    ids[i] = id;  // FirstOrDefault() of an empty sequence is 0; a truth with clusterId 0 also counts as none
+    out += id == 0;
+  }
+  if (outliers) *outliers = out;
+  return ORC_OK;
+}
+
 int orc_match(const double* centers, int32_t K, const double* truths, int32_t T, const double M[16],
               double max_dist, double* mxyz, uint8_t* is_matched, int32_t* nearest, double* nearest_dist,
               int32_t* count_matched) {

@@ -147,6 +147,10 @@ int orc_min_circle(const double* pts, int64_t cnt, double center[2], double* rad
 int orc_get_circles(const double* xy, const int32_t* labels, const int64_t* order, int64_t m, int32_t K,
                     double* centers, double* radius, uint8_t* valid, int32_t* hull_n);
 
+/* MainForm.refreshClusList (FrmMain.cs:3437-3467): truth-guided assignment of every raw point. */
+int orc_assign_truths(const double* motor, int64_t n, const double* truths_xy, const int32_t* truth_ids, int32_t T,
+                      double radius, int32_t* ids, int64_t* outliers);
+
 /* calMatchedCoords + RecorrectMatchingPtsByDistance (FrmMain.cs:3572-3618, :829-835). */
 int orc_match(const double* centers, int32_t K, const double* truths, int32_t T,
               const double M[16], double max_dist, double* matched_xyz, uint8_t* is_matched,

@@ -110,3 +110,21 @@ def test_minimal_bounding_circles(vcp_ctx, oracle):
     with pytest.raises(N.VcpError) as e:
         vcp_ctx.mcc(xy, lab + 5, 2)
     assert e.value.code == -4
+
+
+def test_truth_guided_assignment(vcp_ctx, oracle):
+    """MainForm.refreshClusList: nearest truth within the radius, last one wins ties."""
+    rng = np.random.default_rng(8)
+    d = synth.config_cloud(500_000, seed=31)
+    T = 300
+    txy = rng.random((T, 2)) * d["motor_extent"]
+    txy[50] = txy[10]                      # duplicated truth: equal distances -> the later one (50) wins
+    tids = np.arange(1, T + 1, dtype=np.int32)
+    tids[7] = 0                            # a truth with clusterId 0 behaves like "none"
+    for radius in (2.0, 20.0):
+        o_ids, o_out = oracle.assign_truths(d["motor"], txy, tids, radius)
+        g_ids, g_out = vcp_ctx.assign_truths(d["motor"], txy, tids, radius)
+        assert np.array_equal(o_ids, g_ids) and o_out == g_out
+    assert (g_ids == 51).any() and not (g_ids == 11).any()
+    ids, out = vcp_ctx.assign_truths(d["motor"][:10], np.zeros((0, 2)), np.zeros(0, np.int32), 1.0)
+    assert out == 10 and not ids.any()

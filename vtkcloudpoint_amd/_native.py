@@ -24,7 +24,7 @@ SYMBOLS = [
     "vcp_dbscan", "vcp_dbscan_dev", "vcp_dbscan_blocks", "vcp_blocks_begin", "vcp_blocks_begin_dev",
     "vcp_blocks_share", "vcp_blocks_cluster_dev", "vcp_blocks_finish_dev", "vcp_centroids", "vcp_centroids_dev",
     "vcp_merge_centroids", "vcp_refresh_by_dictionary", "vcp_icp", "vcp_icp_dev", "vcp_icp_sums",
-    "vcp_match", "vcp_mcc",
+    "vcp_match", "vcp_mcc", "vcp_assign_truths",
 ]
 
 
@@ -305,3 +305,14 @@ class Context:
         self._chk(lib().vcp_mcc(self._h, _ptr(xy), _ptr(labels), _ptr(order), C.c_int64(m), C.c_int64(n), C.c_int32(K),
                                 _ptr(centers), _ptr(radius), _ptr(valid), _ptr(hn)))
         return dict(centers=centers, radius=radius, valid=valid, hull_n=hn)
+
+    def assign_truths(self, motor, truths_xy, truth_ids, radius):
+        """MainForm.refreshClusList: (ids [n], number of points with no truth within radius)."""
+        motor = _f64(motor, 2)
+        truths_xy = _f64(truths_xy, 2)
+        truth_ids = np.ascontiguousarray(truth_ids, np.int32)
+        ids = np.zeros(len(motor), np.int32)
+        out = C.c_int64(0)
+        self._chk(lib().vcp_assign_truths(self._h, _ptr(motor), C.c_int64(len(motor)), _ptr(truths_xy), _ptr(truth_ids),
+                                          C.c_int32(len(truth_ids)), C.c_double(radius), _ptr(ids), C.byref(out)))
+        return ids, out.value

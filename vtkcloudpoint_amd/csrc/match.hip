@@ -51,7 +51,78 @@ __global__ __launch_bounds__(MT) void k_match(const double* __restrict__ centers
   unsigned long long b = __ballot(hit);
   if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (uint32_t)__popcll(b));
 }
+// MainForm.refreshClusList (FrmMain.cs:3437-3467): nearest truth within `radius` per raw point; among equal
+// distances the LAST truth in list order wins (OrderByDescending + Reverse), id 0 = none.
+__global__ __launch_bounds__(256) void k_assign_truths(const double* __restrict__ motor, int64_t n,
+                                                      const double* __restrict__ txy, const int32_t* __restrict__ tid,
+                                                      int T, double radius, int32_t* __restrict__ ids,
+                                                      unsigned long long* __restrict__ outliers) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  bool none = false;
+  if (i < n) {
+    const double2 p = *reinterpret_cast<const double2*>(motor + 2 * i);
+    int32_t id = 0;
+    double best = 0;
+    bool have = false;
+    for (int s = 0; s < T; s++) {
+      const double ax = txy[2 * s] - p.x, ay = txy[2 * s + 1] - p.y;
+      const double d = sqrt(ax * ax + ay * ay);
+      if (d < radius && (!have || d <= best)) {
+        best = d;
+        id = tid[s];
+        have = true;
+      }
+    }
+    ids[i] = id;
+    none = id == 0;
+  }
+  __shared__ unsigned wc[4];
+  unsigned long long b = __ballot(none);
+  if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = (unsigned)__popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned t = wc[0] + wc[1] + wc[2] + wc[3];
+    if (t) atomicAdd(&outliers[blockIdx.x & 31], (unsigned long long)t);
+  }
+}
 }  // namespace
+
+extern "C" int vcp_assign_truths(vcp_ctx* ctx, const double* motor, int64_t n, const double* truths_xy,
+                                 const int32_t* truth_ids, int32_t T, double radius, int32_t* ids, int64_t* outliers) {
+  if (!ctx) return VCP_ERR_ARG;
+  if (n < 0 || T < 0 || (n > 0 && (!motor || !ids)) || (T > 0 && (!truths_xy || !truth_ids)))
+    return vcp_fail(ctx, VCP_ERR_ARG, "bad argument");
+  if (outliers) *outliers = 0;
+  if (n == 0) return VCP_OK;
+  VCP_TRY(vcp_bind(ctx));
+  hipStream_t st = ctx->stream;
+  const size_t tt = (size_t)(T > 0 ? T : 1);
+  VCP_TRY(vcp_ensure(ctx, ctx->b_in0, (size_t)n * 16));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_in2, tt * 16));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_in3, tt * 4));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_out0, (size_t)n * 4));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_out2, 32 * 8));
+  VCP_HIP(ctx, hipMemcpyAsync(ctx->b_in0.p, motor, (size_t)n * 16, hipMemcpyHostToDevice, st));
+  if (T > 0) {
+    VCP_HIP(ctx, hipMemcpyAsync(ctx->b_in2.p, truths_xy, (size_t)T * 16, hipMemcpyHostToDevice, st));
+    VCP_HIP(ctx, hipMemcpyAsync(ctx->b_in3.p, truth_ids, (size_t)T * 4, hipMemcpyHostToDevice, st));
+  }
+  VCP_HIP(ctx, hipMemsetAsync(ctx->b_out2.p, 0, 32 * 8, st));
+  hipLaunchKernelGGL(k_assign_truths, dim3(vcp_blocks(n, 256)), dim3(256), 0, st, ctx->b_in0.as<double>(), n,
+                     ctx->b_in2.as<double>(), ctx->b_in3.as<int32_t>(), T, radius, ctx->b_out0.as<int32_t>(),
+                     ctx->b_out2.as<unsigned long long>());
+  VCP_HIP(ctx, hipGetLastError());
+  unsigned long long* hp = reinterpret_cast<unsigned long long*>(ctx->pinned);
+  VCP_HIP(ctx, hipMemcpyAsync(ids, ctx->b_out0.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  VCP_HIP(ctx, hipMemcpyAsync(hp, ctx->b_out2.p, 32 * 8, hipMemcpyDeviceToHost, st));
+  VCP_HIP(ctx, hipStreamSynchronize(st));
+  if (outliers) {
+    unsigned long long t = 0;
+    for (int k = 0; k < 32; k++) t += hp[k];
+    *outliers = (int64_t)t;
+  }
+  return VCP_OK;
+}
 
 extern "C" int vcp_match(vcp_ctx* ctx, const double* centers, int32_t K, const double* truths, int32_t T,
                          const double M[16], double max_dist, double* matched_xyz, uint8_t* is_matched,

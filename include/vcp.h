@@ -182,6 +182,18 @@ int vcp_icp_dev(vcp_ctx* ctx, const double* d_model, int64_t nm, const double* d
 int vcp_icp_sums(vcp_ctx* ctx, const double* model, int64_t nm, const double* data, int64_t nd,
                  const double R[9], const double T[3], double sums[16], int32_t* nn);
 
+/* "VTK-like" ICP: the configuration MainForm.ICP() gives VTK's closed
+ * vtkIterativeClosestPointTransform (FrmMain.cs:851-862), behaviour per the VTK 5.0 header
+ * (vtkIterativeClosestPointTransform.h:49-180): landmarks = every step-th source point (step = ns /
+ * max_landmarks when ns > max_landmarks; VTK's default cap is 200), optional start by matching centroids,
+ * exactly max_iter rounds (the reference sets 100 and leaves the mean-distance check off), rigid body.
+ * source [ns*3] (the reference feeds (tmp_X, tmp_Y, 0), Tools.cs:696-703), target [nt*3]; M = the accumulated
+ * 4x4 row-major matrix (what icp.GetMatrix() returns, FrmMain.cs:862); mean_dist = RMS landmark-to-closest
+ * distance seen by the last round.  PARITY UNPINNED against VTK itself (sources not in the reference tree). */
+int vcp_icp_vtklike(vcp_ctx* ctx, const double* source, int64_t ns, const double* target, int64_t nt,
+                    int max_iter, int max_landmarks, int start_by_matching_centroids, double M[16],
+                    double* mean_dist, int32_t* iters);
+
 /* -- minimal bounding circles ---------------------------------------------
  * Replaces Tools.getCircles (BC/Tools.cs:394-409) / Geometry.FindMinimalBoundingCircle
  * (BC/Geometry.cs:247-319; gift-wrap hull :122-208, circle through 2 or 3 hull points :260-312): for

@@ -253,6 +253,18 @@ def get_circles(xy, labels, K, order=None):
     return dict(centers=centers, radius=radius, valid=valid, hull_n=hn)
 
 
+def icp_vtklike(source, target, max_iter=100, max_landmarks=200, start_by_centroids=True):
+    source = _f64(source, 3)
+    target = _f64(target, 3)
+    M = np.zeros(16)
+    md = C.c_double(0)
+    it = C.c_int32(0)
+    _chk(lib().orc_icp_vtklike(_p(source, C.c_double), C.c_int64(len(source)), _p(target, C.c_double),
+                               C.c_int64(len(target)), int(max_iter), int(max_landmarks), int(start_by_centroids),
+                               _p(M, C.c_double), C.byref(md), C.byref(it)))
+    return dict(M=M.reshape(4, 4), mean_dist=md.value, iters=it.value)
+
+
 def assign_truths(motor, truths_xy, truth_ids, radius):
     motor = _f64(motor, 2)
     truths_xy = _f64(truths_xy, 2)

@@ -1171,6 +1171,58 @@ int orc_get_circles(const double* xy, const int32_t* labels, const int64_t* orde
   return ORC_OK;
 }
 
+// "VTK-like" ICP: the knobs FrmMain.ICP() sets on vtkIterativeClosestPointTransform
+// (FrmMain.cs:851-862: RigidBody, MaximumNumberOfIterations 100, StartByMatchingCentroidsOn, mean-distance check
+// left off) following the header-documented behaviour (vtk/include/vtk-5.0/vtkIterativeClosestPointTransform.h
+// :49-180): landmarks = every step-th source point, step = ns / max_landmarks when ns > max_landmarks; optional
+// initial translation target centroid - source centroid; then max_iter rounds of closest target point (vertex)
+// + rigid landmark transform (Horn), accumulated.  PARITY UNPINNED: VTK 5.0's sources are not in the tree.
+int orc_icp_vtklike(const double* source, int64_t ns, const double* target, int64_t nt, int max_iter,
+                    int max_landmarks, int start_by_centroids, double M[16], double* mean_dist, int32_t* iters_o) {
+  if (ns <= 0 || nt <= 0) return ORC_ERR_EMPTY;
+  if (max_iter < 1 || max_landmarks < 1) return ORC_ERR_ARG;
+  int64_t step = 1;
+  if (ns > max_landmarks) step = ns / max_landmarks;
+  int64_t nb = ns / step;
+  std::vector<double> a(3 * nb);
+  for (int64_t i = 0, j = 0; i < nb; i++, j += step)
+    for (int c = 0; c < 3; c++) a[3 * i + c] = source[3 * j + c];
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, T[3] = {0, 0, 0};
+  if (start_by_centroids) {
+    double cs[3], ct[3];
+    orc_mean3(source, ns, cs);
+    orc_mean3(target, nt, ct);
+    for (int c = 0; c < 3; c++) T[c] = ct[c] - cs[c];
+  }
+  std::vector<double> P(3 * nb);
+  int it = 0;
+  double md = 0;
+  for (;;) {
+    orc_trans_point(a.data(), nb, R, T, P.data());
+    double s[16], R1[9], T1[3];
+    orc_icp_sums(target, nt, P.data(), nb, s);
+    int rc = orc_horn_from_sums(s, nb, R1, T1);
+    if (rc) return rc;
+    double tR[9], tT[3];
+    mul33(R1, R, tR);
+    mul31(R1, T, tT);
+    std::memcpy(R, tR, sizeof(tR));
+    for (int c = 0; c < 3; c++) T[c] = tT[c] + T1[c];
+    md = std::sqrt(s[15] / (double)nb);  // RMS landmark-to-closest distance before this round's update
+    it++;
+    if (it >= max_iter) break;
+  }
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) M[4 * r + c] = R[3 * r + c];
+    M[4 * r + 3] = T[r];
+  }
+  M[12] = M[13] = M[14] = 0;
+  M[15] = 1;
+  if (mean_dist) *mean_dist = md;
+  if (iters_o) *iters_o = it;
+  return ORC_OK;
+}
+
 // MainForm.refreshClusList (FrmMain.cs:3437-3467): per raw point the nearest truth point
 // with sqrt((tmp_X - motor_x)^2 + (tmp_Y - motor_y)^2) < radius; OrderByDescending(DISTANCE).Reverse() makes the
 // LAST truth in list order win among equal distances; id = that truth's clusterId, 0 = none ("yedian").

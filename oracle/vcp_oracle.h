@@ -147,6 +147,10 @@ int orc_min_circle(const double* pts, int64_t cnt, double center[2], double* rad
 int orc_get_circles(const double* xy, const int32_t* labels, const int64_t* order, int64_t m, int32_t K,
                     double* centers, double* radius, uint8_t* valid, int32_t* hull_n);
 
+/* "VTK-like" ICP: the configuration of FrmMain.ICP() (FrmMain.cs:851-862) per the VTK 5.0 header; unpinned. */
+int orc_icp_vtklike(const double* source, int64_t ns, const double* target, int64_t nt, int max_iter,
+                    int max_landmarks, int start_by_centroids, double M[16], double* mean_dist, int32_t* iters);
+
 /* MainForm.refreshClusList (FrmMain.cs:3437-3467): truth-guided assignment of every raw point. */
 int orc_assign_truths(const double* motor, int64_t n, const double* truths_xy, const int32_t* truth_ids, int32_t T,
                       double radius, int32_t* ids, int64_t* outliers);

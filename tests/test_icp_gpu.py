@@ -62,3 +62,23 @@ def test_icp_errors(vcp_ctx):
     # empty data: nothing to match, one round, R/T untouched (BaseClass/ICP.cs: loop body divides by 0)
     g = vcp_ctx.icp(np.zeros((3, 3)), np.zeros((0, 3)))
     assert g["iters"] == 1
+
+
+def test_vtklike_icp_configuration(vcp_ctx, oracle):
+    """MainForm.ICP()'s configuration (FrmMain.cs:851-862): 2-D inputs (x, y, 0), centroid start, landmark
+    subsampling, 100 fixed rounds.  Checked against the oracle's restatement of the header-documented behaviour
+    (VTK itself is a closed binary here: unpinned) and against the known planar transform."""
+    rng = np.random.default_rng(5)
+    truth = np.c_[rng.random((150, 2)) * 400, np.zeros(150)]
+    t = np.deg2rad(1.5)
+    Rz = np.array([[np.cos(t), -np.sin(t), 0], [np.sin(t), np.cos(t), 0], [0, 0, 1]])
+    cent = (truth[rng.integers(0, 150, 900)] - [200, 200, 0]) @ Rz.T + [203, 198.5, 0]  # centroids = moved truths
+    for ml in (200, 5000):
+        g = vcp_ctx.icp_vtklike(cent, truth, 100, ml, True)
+        o = oracle.icp_vtklike(cent, truth, 100, ml, True)
+        assert g["iters"] == o["iters"] == 100
+        assert np.abs(g["M"] - o["M"]).max() < TOL and abs(g["mean_dist"] - o["mean_dist"]) < TOL
+        moved = cent @ g["M"][:3, :3].T + g["M"][:3, 3]
+        nn = oracle.find_closest(truth, moved)
+        assert np.abs(moved - truth[nn]).max() < 1e-6 and g["mean_dist"] < 1e-6
+        assert abs(g["M"][2, 2] - 1) < 1e-9 and np.abs(g["M"][2, :2]).max() < 1e-9  # planar input: rotation about z

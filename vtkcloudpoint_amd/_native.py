@@ -24,7 +24,7 @@ SYMBOLS = [
     "vcp_dbscan", "vcp_dbscan_dev", "vcp_dbscan_blocks", "vcp_blocks_begin", "vcp_blocks_begin_dev",
     "vcp_blocks_share", "vcp_blocks_cluster_dev", "vcp_blocks_finish_dev", "vcp_centroids", "vcp_centroids_dev",
     "vcp_merge_centroids", "vcp_refresh_by_dictionary", "vcp_icp", "vcp_icp_dev", "vcp_icp_sums",
-    "vcp_match", "vcp_mcc", "vcp_assign_truths",
+    "vcp_match", "vcp_mcc", "vcp_assign_truths", "vcp_icp_vtklike",
 ]
 
 
@@ -316,3 +316,15 @@ class Context:
         self._chk(lib().vcp_assign_truths(self._h, _ptr(motor), C.c_int64(len(motor)), _ptr(truths_xy), _ptr(truth_ids),
                                           C.c_int32(len(truth_ids)), C.c_double(radius), _ptr(ids), C.byref(out)))
         return ids, out.value
+
+    def icp_vtklike(self, source, target, max_iter=100, max_landmarks=200, start_by_centroids=True):
+        """MainForm.ICP() (FrmMain.cs:841-907) without VTK: returns dict(M 4x4, mean_dist, iters)."""
+        source = _f64(source, 3)
+        target = _f64(target, 3)
+        M = np.zeros(16)
+        md = C.c_double(0)
+        it = C.c_int32(0)
+        self._chk(lib().vcp_icp_vtklike(self._h, _ptr(source), C.c_int64(len(source)), _ptr(target),
+                                        C.c_int64(len(target)), int(max_iter), int(max_landmarks),
+                                        int(start_by_centroids), _ptr(M), C.byref(md), C.byref(it)))
+        return dict(M=M.reshape(4, 4), mean_dist=md.value, iters=it.value)

@@ -11,6 +11,7 @@
 // Algorithmic bytes: 24 B per data point per round (binary64 xyz read once; the model stays in cache).
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 #include "vcp_ctx.hpp"
 
@@ -297,6 +298,76 @@ int vcp_icp(vcp_ctx* ctx, const double* model, int64_t nm, const double* data, i
   if (nd > 0) VCP_HIP(ctx, hipMemcpyAsync(ctx->b_in2.p, data, (size_t)nd * 24, hipMemcpyHostToDevice, ctx->stream));
   return vcp_icp_dev(ctx, ctx->b_in0.as<double>(), nm, ctx->b_in2.as<double>(), nd, tol, max_iter, stop_rule, R, T,
                      sse, rmse, iters);
+}
+
+// "VTK-like" configuration of the same loop: what MainForm.ICP() asks of
+// vtkIterativeClosestPointTransform (FrmMain.cs:851-862: RigidBody, 100 iterations, StartByMatchingCentroidsOn,
+// no mean-distance check), following the VTK 5.0 header (vtkIterativeClosestPointTransform.h:49-180): landmarks =
+// every step-th source point (step = ns / max_landmarks when ns > max_landmarks), optional initial translation
+// target centroid - source centroid, max_iter rounds, accumulated 4x4 matrix.  VTK's sources are not in the
+// reference tree: behaviour per the header only, PARITY UNPINNED against VTK itself.
+int vcp_icp_vtklike(vcp_ctx* ctx, const double* source, int64_t ns, const double* target, int64_t nt, int max_iter,
+                    int max_landmarks, int start_by_matching_centroids, double M[16], double* mean_dist,
+                    int32_t* iters_o) {
+  if (!ctx) return VCP_ERR_ARG;
+  if (ns <= 0 || nt <= 0) return vcp_fail(ctx, VCP_ERR_EMPTY, "empty source or target");
+  if (max_iter < 1 || max_landmarks < 1 || !source || !target || !M) return vcp_fail(ctx, VCP_ERR_ARG, "bad argument");
+  if (nt >= 0x7FFFFFFFLL) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "target too large");
+  VCP_TRY(vcp_bind(ctx));
+  vcp_phase_reset(ctx);
+  int64_t step = 1;
+  if (ns > max_landmarks) step = ns / max_landmarks;
+  const int64_t nb = ns / step;
+  std::vector<double> a((size_t)3 * nb);
+  for (int64_t i = 0, j = 0; i < nb; i++, j += step)
+    for (int c = 0; c < 3; c++) a[3 * i + c] = source[3 * j + c];
+  Xf xf;
+  identity(xf);
+  if (start_by_matching_centroids) {  // sequential binary64 means over ALL points of both sets
+    double cs[3] = {0, 0, 0}, ct[3] = {0, 0, 0};
+    for (int64_t i = 0; i < ns; i++)
+      for (int c = 0; c < 3; c++) cs[c] += source[3 * i + c];
+    for (int64_t i = 0; i < nt; i++)
+      for (int c = 0; c < 3; c++) ct[c] += target[3 * i + c];
+    for (int c = 0; c < 3; c++) xf.T[c] = ct[c] / (double)nt - cs[c] / (double)ns;
+  }
+  VCP_TRY(vcp_ensure(ctx, ctx->b_in0, (size_t)nt * 24));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_in2, (size_t)nb * 24));
+  VCP_HIP(ctx, hipMemcpyAsync(ctx->b_in0.p, target, (size_t)nt * 24, hipMemcpyHostToDevice, ctx->stream));
+  VCP_HIP(ctx, hipMemcpyAsync(ctx->b_in2.p, a.data(), (size_t)nb * 24, hipMemcpyHostToDevice, ctx->stream));
+  int it = 0;
+  double md = 0;
+  for (;;) {
+    double s[16], R1[9], T1[3];
+    VCP_TRY(icp_pass(ctx, ctx->b_in0.as<double>(), nt, ctx->b_in2.as<double>(), nb, xf, s, nullptr));
+    if (!horn(s, nb, R1, T1)) return vcp_fail(ctx, VCP_ERR_ARG, "Horn solve failed (non-finite sums)");
+    double tR[9], tT[3];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        double acc = 0.0;
+        for (int k = 0; k < 3; k++) acc += R1[3 * i + k] * xf.R[3 * k + j];
+        tR[3 * i + j] = acc;
+      }
+    for (int i = 0; i < 3; i++) {
+      double acc = 0.0;
+      for (int k = 0; k < 3; k++) acc += R1[3 * i + k] * xf.T[k];
+      tT[i] = acc + T1[i];
+    }
+    std::memcpy(xf.R, tR, sizeof(tR));
+    std::memcpy(xf.T, tT, sizeof(tT));
+    md = std::sqrt(s[15] / (double)nb);
+    it++;
+    if (it >= max_iter) break;
+  }
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) M[4 * r + c] = xf.R[3 * r + c];
+    M[4 * r + 3] = xf.T[r];
+  }
+  M[12] = M[13] = M[14] = 0;
+  M[15] = 1;
+  if (mean_dist) *mean_dist = md;
+  if (iters_o) *iters_o = it;
+  return VCP_OK;
 }
 
 int vcp_icp_sums(vcp_ctx* ctx, const double* model, int64_t nm, const double* data, int64_t nd, const double R[9],

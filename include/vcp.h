@@ -213,6 +213,17 @@ int vcp_match(vcp_ctx* ctx, const double* centers, int32_t K, const double* trut
               const double M[16], double max_dist, double* matched_xyz, uint8_t* is_matched,
               int32_t* nearest, double* nearest_dist, int32_t* count_matched);
 
+/* -- import conversion + duplicate removal ------------------------------------
+ * Replaces the per-row work of MainForm.AddFolder for scan points (FrmMain.cs:1011-1090, typpe 1 / 2):
+ * rows [n*3] = (motor_x, motor_y, Distance) as parsed from the tab-separated text (BC/FileMap.cs:16-33);
+ * rows with Distance == 0 or > 1000 are filtered (:1011); X,Y,Z by the spherical conversion of :1025-1062 with
+ * the zero angles x_angle, y_angle and the axis choices xdir, ydir (1 up, 2 right, 3 down, 4 left); with
+ * dedupe != 0 a row whose (tmpx,tmpy,tmpz) equals that of an earlier kept row is a duplicate (:1063-1068; the
+ * C#'s O(n^2) FindAll becomes a device hash table).  xyz [n*3] and state [n] (0 filtered, 1 kept, 2 duplicate)
+ * are written for every row in input order.  dedupe needs the ImportPts defaults xdir = 2, ydir = 1. */
+int vcp_import_convert(vcp_ctx* ctx, const double* rows, int64_t n, double x_angle, double y_angle, int xdir,
+                       int ydir, int dedupe, double* xyz, uint8_t* state, int64_t* kept, int64_t* duplicates);
+
 /* -- truth-guided assignment -------------------------------------------------
  * Replaces the query of MainForm.refreshClusList (FrmMain.cs:3437-3467): per raw point (motor_x, motor_y)
  * the nearest truth (tmp_X, tmp_Y) with Euclidean distance < radius; among equal distances the LAST truth

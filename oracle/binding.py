@@ -253,6 +253,18 @@ def get_circles(xy, labels, K, order=None):
     return dict(centers=centers, radius=radius, valid=valid, hull_n=hn)
 
 
+def import_convert(rows, x_angle=0.0, y_angle=0.0, xdir=2, ydir=1, dedupe=True, literal=False):
+    rows = _f64(rows, 3)
+    n = len(rows)
+    xyz = np.zeros((n, 3))
+    state = np.zeros(n, np.uint8)
+    kept, dup = C.c_int64(0), C.c_int64(0)
+    _chk(lib().orc_import_convert(_p(rows, C.c_double), C.c_int64(n), C.c_double(x_angle), C.c_double(y_angle),
+                                  int(xdir), int(ydir), int(dedupe), int(literal), _p(xyz, C.c_double),
+                                  _p(state, C.c_uint8), C.byref(kept), C.byref(dup)))
+    return dict(xyz=xyz, state=state, kept=kept.value, duplicates=dup.value)
+
+
 def icp_vtklike(source, target, max_iter=100, max_landmarks=200, start_by_centroids=True):
     source = _f64(source, 3)
     target = _f64(target, 3)

@@ -1171,6 +1171,93 @@ int orc_get_circles(const double* xy, const int32_t* labels, const int64_t* orde
   return ORC_OK;
 }
 
+// Import conversion + duplicate removal: MainForm.AddFolder, FrmMain.cs:1011-1090, for the
+// scan-point types 1 (drop duplicates) and 2 (keep them).  rows = (motor_x, motor_y, Distance).
+// state: 0 = filtered (:1011 Distance == 0 or > 1000), 1 = kept, 2 = duplicate (:1065-1067: an earlier KEPT point p
+// with p.X == tmpx && p.Y == tmpy && p.Z == tmpz -- the stored, direction-mapped X,Y against the unmapped tmpx,tmpy).
+// literal != 0 runs the C#'s O(n^2) FindAll; otherwise a hash on the triple (valid when xdir = 2, ydir = 1, the
+// ImportPts defaults, where stored and queried triples coincide).
+int orc_import_convert(const double* rows, int64_t n, double x_angle, double y_angle, int xdir, int ydir, int dedupe,
+                       int literal, double* xyz, uint8_t* state, int64_t* kept_o, int64_t* dup_o) {
+  if (n < 0 || xdir < 1 || xdir > 4 || ydir < 1 || ydir > 4) return ORC_ERR_ARG;
+  if (dedupe && !literal && !(xdir == 2 && ydir == 1)) return ORC_ERR_ARG;
+  const double PI = 3.14159265358979323846;  // Math.PI
+  int64_t kept = 0, dup = 0;
+  std::vector<int64_t> keptidx;
+  struct K3 {
+    double a, b, c;
+  };
+  auto canon = [](double v) { return v == 0 ? 0.0 : v; };
+  std::vector<std::pair<uint64_t, int64_t>> table;  // open addressing: (hash+1, index)
+  size_t cap = 1;
+  while (cap < (size_t)(2 * n + 16)) cap <<= 1;
+  if (dedupe && !literal) table.assign(cap, {0, -1});
+  auto hash3 = [&](double a, double b, double c) {
+    uint64_t h = 1469598103934665603ull;
+    for (double v : {canon(a), canon(b), canon(c)}) {
+      uint64_t u;
+      std::memcpy(&u, &v, 8);
+      h = (h ^ u) * 1099511628211ull;
+      h ^= h >> 29;
+    }
+    return h;
+  };
+  for (int64_t i = 0; i < n; i++) {
+    const double mx = rows[3 * i], my = rows[3 * i + 1], D = rows[3 * i + 2];
+    xyz[3 * i] = xyz[3 * i + 1] = xyz[3 * i + 2] = 0;
+    if (D == 0 || D > 1000) {
+      state[i] = 0;
+      continue;
+    }
+    const double yangjiao = (-2) * (mx - x_angle) / 180 * PI;
+    const double fangweijiao = 2 * (my - y_angle) / 180 * PI;
+    const double tmpx = D * std::cos(yangjiao) * std::sin(fangweijiao);
+    const double tmpy = D * std::sin(yangjiao) * std::cos(fangweijiao);
+    const double tmpz = D * std::cos(yangjiao);
+    const double pick[5] = {0, tmpy, tmpx, -tmpy, -tmpx};
+    const double X = pick[xdir], Y = pick[ydir], Z = tmpz;
+    xyz[3 * i] = X;
+    xyz[3 * i + 1] = Y;
+    xyz[3 * i + 2] = Z;
+    bool isdup = false;
+    if (dedupe) {
+      if (literal) {
+        for (int64_t j : keptidx)
+          if (xyz[3 * j] == tmpx && xyz[3 * j + 1] == tmpy && xyz[3 * j + 2] == tmpz) {
+            isdup = true;
+            break;
+          }
+      } else if (tmpx == tmpx && tmpy == tmpy && tmpz == tmpz) {  // NaN never equals anything
+        uint64_t h = hash3(tmpx, tmpy, tmpz);
+        size_t sl = h & (cap - 1);
+        for (;;) {
+          if (table[sl].second < 0) {
+            table[sl] = {h, i};
+            break;
+          }
+          int64_t j = table[sl].second;
+          if (xyz[3 * j] == tmpx && xyz[3 * j + 1] == tmpy && xyz[3 * j + 2] == tmpz) {
+            isdup = true;
+            break;
+          }
+          sl = (sl + 1) & (cap - 1);
+        }
+      }
+    }
+    if (isdup) {
+      state[i] = 2;
+      dup++;
+    } else {
+      state[i] = 1;
+      kept++;
+      if (dedupe && literal) keptidx.push_back(i);
+    }
+  }
+  if (kept_o) *kept_o = kept;
+  if (dup_o) *dup_o = dup;
+  return ORC_OK;
+}
+
 // "VTK-like" ICP: the knobs FrmMain.ICP() sets on vtkIterativeClosestPointTransform
 // (FrmMain.cs:851-862: RigidBody, MaximumNumberOfIterations 100, StartByMatchingCentroidsOn, mean-distance check
 // left off) following the header-documented behaviour (vtk/include/vtk-5.0/vtkIterativeClosestPointTransform.h

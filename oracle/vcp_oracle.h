@@ -147,6 +147,10 @@ int orc_min_circle(const double* pts, int64_t cnt, double center[2], double* rad
 int orc_get_circles(const double* xy, const int32_t* labels, const int64_t* order, int64_t m, int32_t K,
                     double* centers, double* radius, uint8_t* valid, int32_t* hull_n);
 
+/* MainForm.AddFolder's conversion + duplicate removal for scan points (FrmMain.cs:1011-1090). */
+int orc_import_convert(const double* rows, int64_t n, double x_angle, double y_angle, int xdir, int ydir, int dedupe,
+                       int literal, double* xyz, uint8_t* state, int64_t* kept, int64_t* duplicates);
+
 /* "VTK-like" ICP: the configuration of FrmMain.ICP() (FrmMain.cs:851-862) per the VTK 5.0 header; unpinned. */
 int orc_icp_vtklike(const double* source, int64_t ns, const double* target, int64_t nt, int max_iter,
                     int max_landmarks, int start_by_centroids, double M[16], double* mean_dist, int32_t* iters);

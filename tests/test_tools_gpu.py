@@ -128,3 +128,29 @@ def test_truth_guided_assignment(vcp_ctx, oracle):
     assert (g_ids == 51).any() and not (g_ids == 11).any()
     ids, out = vcp_ctx.assign_truths(d["motor"][:10], np.zeros((0, 2)), np.zeros(0, np.int32), 1.0)
     assert out == 10 and not ids.any()
+
+
+def test_import_conversion_and_duplicate_removal(vcp_ctx, oracle):
+    """MainForm.AddFolder: Distance filter, spherical -> Cartesian, first-occurrence dedupe."""
+    rng = np.random.default_rng(12)
+    n = 400_000
+    rows = np.c_[rng.random(n) * 40, rng.random(n) * 40, rng.random(n) * 1100]
+    rows[200000:250000] = rows[0:50000]       # 50k exact duplicates of earlier rows
+    rows[70000] = rows[123]
+    rows[7, 2] = 0.0                          # filtered: Distance == 0
+    o = oracle.import_convert(rows, 1.5, -0.5, 2, 1, True)
+    g = vcp_ctx.import_convert(rows, 1.5, -0.5, 2, 1, True)
+    assert np.array_equal(o["state"], g["state"]) and o["kept"] == g["kept"] and o["duplicates"] == g["duplicates"]
+    assert g["duplicates"] >= 40000 and (g["state"] == 0).sum() > 0.05 * n
+    assert np.allclose(o["xyz"], g["xyz"], rtol=1e-12, atol=1e-9)  # device sin/cos vs host libm: a few ulp
+    # the hash version of the oracle equals the C#'s literal O(n^2) FindAll on a small prefix
+    lit = oracle.import_convert(rows[:6000], 1.5, -0.5, 2, 1, True, literal=True)
+    assert np.array_equal(lit["state"], oracle.import_convert(rows[:6000], 1.5, -0.5, 2, 1, True)["state"])
+    assert np.array_equal(lit["state"], vcp_ctx.import_convert(rows[:6000], 1.5, -0.5, 2, 1, True)["state"])
+    # no dedupe, other axis choices
+    o = oracle.import_convert(rows, 0.0, 0.0, 4, 3, False)
+    g = vcp_ctx.import_convert(rows, 0.0, 0.0, 4, 3, False)
+    assert np.array_equal(o["state"], g["state"]) and np.allclose(o["xyz"], g["xyz"], rtol=1e-12, atol=1e-9)
+    with pytest.raises(N.VcpError) as e:
+        vcp_ctx.import_convert(rows[:10], 0.0, 0.0, 4, 3, True)
+    assert e.value.code == -8

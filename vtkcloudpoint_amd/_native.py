@@ -24,7 +24,7 @@ SYMBOLS = [
     "vcp_dbscan", "vcp_dbscan_dev", "vcp_dbscan_blocks", "vcp_blocks_begin", "vcp_blocks_begin_dev",
     "vcp_blocks_share", "vcp_blocks_cluster_dev", "vcp_blocks_finish_dev", "vcp_centroids", "vcp_centroids_dev",
     "vcp_merge_centroids", "vcp_refresh_by_dictionary", "vcp_icp", "vcp_icp_dev", "vcp_icp_sums",
-    "vcp_match", "vcp_mcc", "vcp_assign_truths", "vcp_icp_vtklike",
+    "vcp_match", "vcp_mcc", "vcp_assign_truths", "vcp_icp_vtklike", "vcp_import_convert",
 ]
 
 
@@ -328,3 +328,15 @@ class Context:
                                         C.c_int64(len(target)), int(max_iter), int(max_landmarks),
                                         int(start_by_centroids), _ptr(M), C.byref(md), C.byref(it)))
         return dict(M=M.reshape(4, 4), mean_dist=md.value, iters=it.value)
+
+    def import_convert(self, rows, x_angle=0.0, y_angle=0.0, xdir=2, ydir=1, dedupe=True):
+        """MainForm.AddFolder per-row work: dict(xyz [n,3], state [n] (0 filtered / 1 kept / 2 duplicate), kept, duplicates)."""
+        rows = _f64(rows, 3)
+        n = len(rows)
+        xyz = np.zeros((n, 3))
+        state = np.zeros(n, np.uint8)
+        kept, dup = C.c_int64(0), C.c_int64(0)
+        self._chk(lib().vcp_import_convert(self._h, _ptr(rows), C.c_int64(n), C.c_double(x_angle), C.c_double(y_angle),
+                                           int(xdir), int(ydir), int(dedupe), _ptr(xyz), _ptr(state), C.byref(kept),
+                                           C.byref(dup)))
+        return dict(xyz=xyz, state=state, kept=kept.value, duplicates=dup.value)

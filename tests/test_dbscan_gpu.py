@@ -86,3 +86,22 @@ def test_unsupported_dead_class(vcp_ctx):
     with pytest.raises(N.VcpError) as e:
         vcp_ctx.dbscan(c, 0.5, 2, N.SIGNED_SUM_2D)
     assert e.value.code == -8
+
+
+def test_whole_cloud_inside_one_eps_ball(vcp_ctx, oracle):
+    """eps >= the bounding-box measure: every pair is a neighbour; the O(n) shortcut equals the literal result."""
+    rng = np.random.default_rng(21)
+    c = rng.random((2000, 3)) * 5
+    cls = (rng.random(2000) < 0.3).astype(np.uint8)
+    lab0 = (rng.integers(1, 4, 2000) * cls).astype(np.int32)
+    for metric, eps in ((0, 10.0), (1, 7.1), (2, 8.7), (0, float("inf"))):
+        for mp in (5, 5000):
+            for args in ((None, None), (cls, lab0), (np.ones(2000, np.uint8), lab0 + 1)):
+                o = oracle.dbscan(c, eps, mp, metric, 3, args[0], args[1], literal=True)
+                g = vcp_ctx.dbscan(c, eps, mp, metric, 3, args[0], args[1])
+                _same(g, o, "metric %d mp %d" % (metric, mp))
+                assert np.array_equal(g["is_core"], o["is_key"])
+    # and it is O(n): a million points with an infinite eps come back at once as a single cluster
+    big = rng.random((1_000_000, 2))
+    g = vcp_ctx.dbscan(big, float("inf"), 10)
+    assert g["cf"] == 1 and (g["labels"] == 1).all() and g["evals"] == (1_000_000 + 1) * 1_000_000

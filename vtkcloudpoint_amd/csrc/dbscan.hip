@@ -42,27 +42,18 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 struct GridP {
   double mn[3];
   double inv_h;
-  int D[3];          // cells per axis
-  uint32_t ncells;   // including the padding of partial tiles
-  int tl;            // log2 of the tile edge in cells (0 = plain x-fastest order)
-  uint32_t NT[3];    // tiles per axis
+  int D[3];         // cells per axis
+  uint32_t ncells;
 };
 
-// linear id of cell (cx,cy,cz): tiles of 2^tl cells per axis are laid out x-fastest, and so are the cells
-// inside a tile: a workgroup's 256 consecutive sorted points then cover a compact patch of the plane (volume)
-// instead of a long thin row strip, so the three (nine) neighbour rows of a point sit close in memory.
+// linear id of cell (cx,cy,cz), x fastest: the 3 cells of a neighbour row are one contiguous position range.
+// (A tile-major order -- tiles of 4..16 cells per axis -- was measured 5-25 % SLOWER on MI355X for these
+// latency-bound search loops, with or without the XCD-aware block map, and was dropped.)
 template <int GD>
 __device__ __forceinline__ uint32_t cell_id(const GridP& g, int cx, int cy, int cz) {
-  const int tl = g.tl;
-  const uint32_t m = (1u << tl) - 1u;
-  uint32_t tile = ((uint32_t)cy >> tl) * g.NT[0] + ((uint32_t)cx >> tl);
-  uint32_t loc = (((uint32_t)cy & m) << tl) | ((uint32_t)cx & m);
-  if (GD == 3) {
-    tile += ((uint32_t)cz >> tl) * g.NT[0] * g.NT[1];
-    loc |= ((uint32_t)cz & m) << (2 * tl);
-    return (tile << (3 * tl)) | loc;
-  }
-  return (tile << (2 * tl)) | loc;
+  uint32_t id = (uint32_t)cy * (uint32_t)g.D[0] + (uint32_t)cx;
+  if (GD == 3) id += (uint32_t)cz * (uint32_t)g.D[0] * (uint32_t)g.D[1];
+  return id;
 }
 
 template <int METRIC>
@@ -124,8 +115,9 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
-__device__ __forceinline__ void block_minmax(double* mn, double* mx, double* __restrict__ out6) {
-  __shared__ double sm[TPB / 64][6];
+// out[0..2] = min, out[3..5] = max, out[6] = number of non-finite coordinates seen
+__device__ __forceinline__ void block_minmax(double* mn, double* mx, double bad, double* __restrict__ out8) {
+  __shared__ double sm[TPB / 64][7];
   int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
   for (int a = 0; a < 3; a++) {
@@ -135,21 +127,24 @@ __device__ __forceinline__ void block_minmax(double* mn, double* mx, double* __r
       sm[w][3 + a] = hi;
     }
   }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) bad += __shfl_down(bad, d, 64);
+  if (lane == 0) sm[w][6] = bad;
   __syncthreads();
-  if (threadIdx.x < 6) {
+  if (threadIdx.x < 7) {
     double v = sm[0][threadIdx.x];
     for (int k = 1; k < TPB / 64; k++)
-      v = threadIdx.x < 3 ? fmin(v, sm[k][threadIdx.x]) : fmax(v, sm[k][threadIdx.x]);
-    out6[threadIdx.x] = v;
+      v = threadIdx.x < 3 ? fmin(v, sm[k][threadIdx.x]) : threadIdx.x < 6 ? fmax(v, sm[k][threadIdx.x]) : v + sm[k][6];
+    out8[threadIdx.x] = v;
   }
 }
 
-// partial[b*6 + a] = min of axis a, partial[b*6 + 3 + a] = max, over finite values only
+// partial[b*8 + a] = min of axis a, partial[b*8 + 3 + a] = max over finite values, partial[b*8 + 6] = #non-finite
 template <int GD, bool GROUPED>
 __global__ __launch_bounds__(TPB) void k_bounds(const double* __restrict__ c, int64_t n, int stride,
                                                const int32_t* __restrict__ group, int glo, int ghi,
                                                double* __restrict__ partial) {
-  double mn[3], mx[3];
+  double mn[3], mx[3], bad = 0;
   for (int a = 0; a < 3; a++) {
     mn[a] = INFINITY;
     mx[a] = -INFINITY;
@@ -165,25 +160,29 @@ __global__ __launch_bounds__(TPB) void k_bounds(const double* __restrict__ c, in
       if (isfinite(v)) {
         mn[a] = fmin(mn[a], v);
         mx[a] = fmax(mx[a], v);
+      } else {
+        bad += 1.0;
       }
     }
   }
-  block_minmax(mn, mx, partial + (size_t)blockIdx.x * 6);
+  block_minmax(mn, mx, bad, partial + (size_t)blockIdx.x * 8);
 }
 
 __global__ __launch_bounds__(TPB) void k_bounds_final(const double* __restrict__ partial, int nb,
                                                      double* __restrict__ out) {
-  double mn[3], mx[3];
+  double mn[3], mx[3], bad = 0;
   for (int a = 0; a < 3; a++) {
     mn[a] = INFINITY;
     mx[a] = -INFINITY;
   }
-  for (int b = threadIdx.x; b < nb; b += TPB)
+  for (int b = threadIdx.x; b < nb; b += TPB) {
     for (int a = 0; a < 3; a++) {
-      mn[a] = fmin(mn[a], partial[b * 6 + a]);
-      mx[a] = fmax(mx[a], partial[b * 6 + 3 + a]);
+      mn[a] = fmin(mn[a], partial[b * 8 + a]);
+      mx[a] = fmax(mx[a], partial[b * 8 + 3 + a]);
     }
-  block_minmax(mn, mx, out);
+    bad += partial[b * 8 + 6];
+  }
+  block_minmax(mn, mx, bad, out);
 }
 
 // ---- grid build -------------------------------------------------------------------------------
@@ -251,34 +250,26 @@ __global__ __launch_bounds__(TPB) void k_scatter(const double* __restrict__ c, i
   if (in_classed) flags[p] = in_classed[i] ? F_CLASSED : 0;  // otherwise flags were zero-filled
 }
 
-// iterate the candidate rows of a cell neighbourhood: f(s, e) for the position range of each x-run of
-// the 3 (9) neighbour rows (a row of 3 cells is one run, or two when it crosses a tile edge); f returns false
-// to stop early.  Runs are NOT visited in increasing position order once tiles are on.
+// iterate the candidate rows of a cell neighbourhood: f(s, e) for the position range of each of the 3 (9)
+// x-rows, in increasing position order; f returns false to stop early.  All row bounds are fetched up front
+// (6 or 18 independent cellstart loads in flight) instead of two dependent loads per row.
 template <int GD, class F>
 __device__ __forceinline__ void for_rows(const int* cc, const GridP& g, const uint32_t* __restrict__ cellstart, F&& f) {
+  constexpr int NR = GD == 3 ? 9 : 3;
   const int x0 = max(cc[0] - 1, 0), x1 = min(cc[0] + 1, g.D[0] - 1);
-  const int y0 = max(cc[1] - 1, 0), y1 = min(cc[1] + 1, g.D[1] - 1);
-  int z0 = 0, z1 = 0;
-  if (GD == 3) {
-    z0 = max(cc[2] - 1, 0);
-    z1 = min(cc[2] + 1, g.D[2] - 1);
+  uint32_t rs[NR], re[NR];
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    const int y = cc[1] + (r % 3) - 1;
+    const int z = GD == 3 ? cc[2] + (r / 3) - 1 : 0;
+    const bool ok = y >= 0 && y < g.D[1] && (GD != 3 || (z >= 0 && z < g.D[2]));
+    const uint32_t base = ok ? cell_id<GD>(g, 0, y, z) : 0u;
+    rs[r] = ok ? cellstart[base + x0] : 0u;
+    re[r] = ok ? cellstart[base + x1 + 1] : 0u;
   }
-  // the x-run [x0,x1] splits where it crosses a tile edge: xs = first cell of the second piece (or x1+1)
-  const int tmask = (1 << g.tl) - 1;
-  int xs = x1 + 1;
-  if (g.tl > 0 && (x0 >> g.tl) != (x1 >> g.tl)) xs = (x1 >> g.tl) << g.tl;  // at most one edge inside 3 cells
-  (void)tmask;
-  for (int z = z0; z <= z1; z++)
-    for (int y = y0; y <= y1; y++) {
-      {
-        const uint32_t a = cell_id<GD>(g, x0, y, z), b = cell_id<GD>(g, xs - 1, y, z);
-        if (!f(cellstart[a], cellstart[b + 1])) return;
-      }
-      if (xs <= x1) {
-        const uint32_t a = cell_id<GD>(g, xs, y, z), b = cell_id<GD>(g, x1, y, z);
-        if (!f(cellstart[a], cellstart[b + 1])) return;
-      }
-    }
+  for (int r = 0; r < NR; r++)
+    if (rs[r] < re[r])
+      if (!f(rs[r], re[r])) return;
 }
 
 // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  The neighbour-search kernels
@@ -849,6 +840,23 @@ __global__ __launch_bounds__(TPB) void k_group_stats(int32_t G, int glo, int ghi
   if (ev) atomicAdd(evals, ev);
 }
 
+// ---- the whole cloud fits inside one eps-ball: every pair is within eps -------------------------------
+// (decided on the host from the bounding box; without this, one cell would hold everything and the search
+// would be O(n^2)).  count = n for every point, so either nobody is core, or everybody is and the unclassed
+// points form ONE cluster cf_in+1 that also relabels every classed point (BaseClass/DBImproved.cs:87).
+__global__ __launch_bounds__(TPB) void k_all_pairs(const uint8_t* __restrict__ in_classed, int64_t n, int core,
+                                                  int have_seed, int32_t cf_in, int32_t* __restrict__ labels,
+                                                  uint8_t* __restrict__ is_core, uint8_t* __restrict__ is_classed) {
+  int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const bool cls = in_classed && in_classed[i];
+  const bool hit = core && have_seed;
+  if (hit) labels[i] = cf_in + 1;
+  else if (!in_classed) labels[i] = 0;
+  if (is_core) is_core[i] = (core && !cls) ? 1 : 0;
+  if (is_classed) is_classed[i] = (cls || hit) ? 1 : 0;
+}
+
 // ---- eps < 0 or NaN: nobody has a neighbour, not even itself ---------------------------------------
 __global__ __launch_bounds__(TPB) void k_unclassed_flag(const uint8_t* __restrict__ in_classed, uint32_t* __restrict__ f,
                                                        int64_t n) {
@@ -899,14 +907,49 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   // 1. bounds over finite coordinates
   vcp_phase(ctx, "bounds");
   const int rb = (int)vcp_blocks(n, TPB, 1024);
-  VCP_TRY(vcp_ensure(ctx, ctx->b_misc, (size_t)(rb * 6 + 64) * sizeof(double)));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_misc, (size_t)(rb * 8 + 64) * sizeof(double)));
   double* d_part = ctx->b_misc.as<double>();
-  double* d_bounds = d_part + (size_t)rb * 6;
+  double* d_bounds = d_part + (size_t)rb * 8;
   hipLaunchKernelGGL((k_bounds<GD, GROUPED>), dim3(rb), dim3(TPB), 0, st, d_coords, n, stride, d_group, glo, ghi, d_part);
   hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(TPB), 0, st, d_part, rb, d_bounds);
   double* h = reinterpret_cast<double*>(ctx->pinned);
-  VCP_HIP(ctx, hipMemcpyAsync(h, d_bounds, 6 * sizeof(double), hipMemcpyDeviceToHost, st));
+  VCP_HIP(ctx, hipMemcpyAsync(h, d_bounds, 7 * sizeof(double), hipMemcpyDeviceToHost, st));
   VCP_HIP(ctx, hipStreamSynchronize(st));
+  const bool all_finite = h[6] == 0.0;
+
+  const double thr = (METRIC == VCP_L1_2D) ? eps : l2_threshold(eps);
+  if (!GROUPED && all_finite) {
+    // monotone rounding: |dx| <= hi-lo on every axis, so the box measure bounds every pair's distance form
+    const double wx = h[3] - h[0], wy = h[4] - h[1], wz = GD == 3 ? h[5] - h[2] : 0.0;
+    const double box = METRIC == VCP_L1_2D ? std::fabs(wx) + std::fabs(wy)
+                       : METRIC == VCP_L2_2D ? wx * wx + wy * wy : wx * wx + wy * wy + wz * wz;
+    if (box <= thr) {
+      vcp_phase(ctx, "all_pairs");
+      VCP_TRY(vcp_ensure(ctx, ctx->b_seedflag, (size_t)(n + 2) * 4));
+      uint32_t* f = ctx->b_seedflag.as<uint32_t>();
+      uint32_t* d_tot = reinterpret_cast<uint32_t*>(d_bounds + 8);
+      unsigned long long unclassed = (unsigned long long)n;
+      if (d_in_classed) {
+        hipLaunchKernelGGL(k_unclassed_flag, dim3(nb), dim3(TPB), 0, st, d_in_classed, f, n);
+        VCP_TRY(vcp_exclusive_scan_u32(ctx, f, f, n, d_tot));
+        uint32_t* hu = reinterpret_cast<uint32_t*>(ctx->pinned) + 32;
+        VCP_HIP(ctx, hipMemcpyAsync(hu, d_tot, 4, hipMemcpyDeviceToHost, st));
+        VCP_HIP(ctx, hipStreamSynchronize(st));
+        unclassed = hu[0];
+      }
+      const int core = n >= (int64_t)min_pts;
+      const int have_seed = unclassed > 0;
+      hipLaunchKernelGGL(k_all_pairs, dim3(nb), dim3(TPB), 0, st, d_in_classed, n, core, have_seed, cf_in, d_labels,
+                         d_is_core, d_is_classed);
+      VCP_HIP(ctx, hipGetLastError());
+      VCP_TRY(vcp_phase_finish(ctx));
+      VCP_HIP(ctx, hipStreamSynchronize(st));
+      const int made = core && have_seed;
+      if (cf_out) *cf_out = cf_in + made;
+      if (dist_evals) *dist_evals = (int64_t)(unclassed + (unsigned long long)made) * n;
+      return VCP_OK;
+    }
+  }
 
   // 2. grid geometry (host): cell edge a hair above eps; coarsen until the cell count fits
   GridP g;
@@ -941,25 +984,7 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   }
   if (ncells > budget) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "grid does not fit the cell budget");
   g.inv_h = std::isinf(cellw) ? 0.0 : 1.0 / cellw;
-  // tile-major cell order; partial tiles are padded (their cells stay empty)
-  // (measured on MI355X: tiles of 4..16 cells are 5-25 % SLOWER than plain x-fastest order for these
-  // latency-bound search loops, so the default is 0; VCP_TILE_LOG2 keeps the experiment reachable)
-  g.tl = getenv("VCP_TILE_LOG2") ? atoi(getenv("VCP_TILE_LOG2")) : 0;
-  for (;;) {
-    int64_t nc = 1;
-    for (int a = 0; a < 3; a++) {
-      g.NT[a] = a < GD ? (uint32_t)((g.D[a] + (1 << g.tl) - 1) >> g.tl) : 1u;
-      nc *= a < GD ? ((int64_t)g.NT[a] << g.tl) : 1;
-    }
-    if (nc <= 2 * budget && nc < ((int64_t)1 << 31)) {
-      ncells = nc;
-      break;
-    }
-    if (g.tl == 0) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "grid does not fit the cell budget");
-    g.tl--;
-  }
   g.ncells = (uint32_t)ncells;
-  const double thr = (METRIC == VCP_L1_2D) ? eps : l2_threshold(eps);
 
   // 3. workspace
   VCP_TRY(vcp_ensure(ctx, ctx->b_cellcnt, (size_t)(ncells + 2) * 4));

@@ -1,14 +1,22 @@
 // icp.hip -- ICP.go_hell_ICP on MI355X (gfx950).
 //
-// Per round ONE fused pass over the data (BaseClass/ICP.cs:195-219 TransPoint, :224-250
-// FindClosestPointSet, :255-273 means, :38-52 sum p y^T, :126-133 SSE): every thread transforms its
-// points with the current R,T, scans the model brute force (wave-uniform index => the model is read
-// through the scalar cache, no LDS needed for a few thousand points), and keeps 16 binary64 partial sums.
-// Sums are reduced wave -> block -> a fixed-order pass over the block partials (no float atomics: the
-// result is run-to-run deterministic).  The 16 sums go to the host, which solves Horn's closed form
-// (the INTENDED arithmetic of :53-124) and composes R,T (:149-177).
+// Per round two launches, no host round trip:
+//   k_icp_pass  one fused pass over the data (BaseClass/ICP.cs:195-219 TransPoint, :224-250 FindClosestPointSet,
+//               :255-273 means, :38-52 sum p y^T, :126-133 SSE): every thread transforms its points with the
+//               current R,T (read from the device-resident state), finds the nearest model point and keeps 16
+//               binary64 partial sums; wave shuffle -> workgroup -> one partial row per workgroup.
+//   k_icp_step  fixed-order reduction of the partial rows (bitwise reproducible, no float atomics), then ONE
+//               thread solves Horn's closed form (the INTENDED arithmetic of :53-124), applies
+//               the stop rule (:149,:180) and composes R <- R1 R, T <- R1 T + T1 (:149-177) in the state.
+// The host enqueues rounds in batches of 8 and reads the 300-byte state back once per batch; kernels of rounds
+// after the stop see state.done and return at once.
 //
-// Algorithmic bytes: 24 B per data point per round (binary64 xyz read once; the model stays in cache).
+// Nearest neighbour: the model index is wave-uniform, so model points come through the scalar cache, four per
+// trip.  Distances are first screened in binary32 (three FMAs per pair) with a rigorous rounding bound; only model points whose
+// binary32 distance is within that bound of the smallest are re-evaluated in binary64, in index order with the
+// C#'s strict `<` -- the chosen index is bit-identical to a full binary64 scan.
+// Algorithmic bytes: 24 B per data point per round; at 1M x 100 the pass is VALU bound, not HBM bound.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -19,10 +27,16 @@ namespace {
 
 constexpr int ITPB = 256;
 constexpr int ICP_MAX_BLOCKS = 1024;
+constexpr int ICP_BATCH = 8;  // rounds enqueued per host synchronisation
 
-struct Xf {
-  double R[9];
-  double T[3];
+enum { MODE_REFERENCE = 0, MODE_VTK = 1, MODE_SUMS_ONLY = 2 };
+
+struct IcpState {
+  double R[9], T[3];
+  double d, pre_d;
+  double sums[16];
+  double dmax, mmax;  // largest |coordinate| of data / model: scale of the binary32 screening bound
+  int round, done, failed, pad;
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -31,9 +45,44 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-__global__ __launch_bounds__(ITPB) void k_icp_pass(const double* __restrict__ model, int nm,
-                                                  const double* __restrict__ data, int64_t nd, Xf xf,
-                                                  double* __restrict__ partial, int32_t* __restrict__ nn) {
+// largest |v| of an array into *out (the bit pattern of a non-negative double orders like the value)
+__global__ __launch_bounds__(ITPB) void k_absmax(const double* __restrict__ a, int64_t n, double* __restrict__ out) {
+  double m = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * ITPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * ITPB) {
+    double v = fabs(a[i]);
+    if (!(v <= m)) m = (v == v) ? v : INFINITY;  // NaN -> infinite scale (everything is re-checked in binary64)
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) m = fmax(m, __shfl_down(m, d, 64));
+  if ((threadIdx.x & 63) == 0)
+    atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(m));
+}
+
+// screening copy of the model: (m0, m1, m2, |m|^2 / 2) in binary32, one 16-byte scalar load per model point
+__global__ __launch_bounds__(ITPB) void k_model32(const double* __restrict__ m, int64_t nm, float4* __restrict__ o) {
+  int64_t j = (int64_t)blockIdx.x * ITPB + threadIdx.x;
+  if (j >= nm) return;
+  const double a = m[3 * j], b = m[3 * j + 1], c = m[3 * j + 2];
+  o[j] = make_float4((float)a, (float)b, (float)c, (float)(0.5 * (a * a + b * b + c * c)));
+}
+
+__global__ __launch_bounds__(ITPB) void k_icp_pass(const double* __restrict__ model, const float4* __restrict__ model32,
+                                                  int nm, const double* __restrict__ data, int64_t nd,
+                                                  const IcpState* __restrict__ st, double* __restrict__ partial,
+                                                  int32_t* __restrict__ nn) {
+  if (st->done) return;
+  double R[9], T[3];
+#pragma unroll
+  for (int k = 0; k < 9; k++) R[k] = st->R[k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) T[k] = st->T[k];
+  // binary32 screening on the score h_j - q.m_j (= (|q - m_j|^2 - |q|^2) / 2, h_j = |m_j|^2 / 2): three FMAs per
+  // model point.  With S = a bound on every |coordinate| involved and u = 2^-24 the computed score is within
+  // 27 u S^2 of the exact one (input conversions 9 u S^2, h_j 4.5 u S^2, three fused roundings 13.5 u S^2), so a
+  // model point can be the binary64 winner only if score <= best score + 54 u S^2; 2^-17 S^2 = 128 u S^2 is used.
+  const double tmax = fmax(fabs(T[0]), fmax(fabs(T[1]), fabs(T[2])));
+  const double S = fmax(st->mmax, tmax + 3.0 * st->dmax);
+  const float tol2 = (float)(S * S * 7.62939453125e-06) * 1.0001f;  // 2^-17 S^2, rounded up
   double s[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) s[k] = 0.0;
@@ -44,21 +93,58 @@ __global__ __launch_bounds__(ITPB) void k_icp_pass(const double* __restrict__ mo
 #pragma unroll
     for (int r = 0; r < 3; r++) {
       double acc = 0.0;
-      acc += xf.R[3 * r] * d0;
-      acc += xf.R[3 * r + 1] * d1;
-      acc += xf.R[3 * r + 2] * d2;
-      p[r] = acc + xf.T[r];
+      acc += R[3 * r] * d0;
+      acc += R[3 * r + 1] * d1;
+      acc += R[3 * r + 2] * d2;
+      p[r] = acc + T[r];
     }
-    // FindClosestPointSet: strict <, lowest model index wins ties
-    double best = (p[0] - model[0]) * (p[0] - model[0]) + (p[1] - model[1]) * (p[1] - model[1]) +
-                  (p[2] - model[2]) * (p[2] - model[2]);
-    int order = 0;
-    for (int j = 1; j < nm; j++) {
-      const double m0 = model[3 * j], m1 = model[3 * j + 1], m2 = model[3 * j + 2];
-      double dd = (p[0] - m0) * (p[0] - m0) + (p[1] - m1) * (p[1] - m1) + (p[2] - m2) * (p[2] - m2);
-      if (dd < best) {
-        best = dd;
-        order = j;
+    const float q0 = (float)p[0], q1 = (float)p[1], q2 = (float)p[2];
+    // pass 1 (binary32): smallest and second smallest screened score, four model points per trip
+    float b1 = INFINITY, b2 = INFINITY;
+    int j1 = 0;
+    int j = 0;
+    for (; j + 3 < nm; j += 4) {
+      float4 mm[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) mm[u] = model32[j + u];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const float sc = __builtin_fmaf(-q0, mm[u].x, __builtin_fmaf(-q1, mm[u].y, __builtin_fmaf(-q2, mm[u].z, mm[u].w)));
+        const bool lt = sc < b1;
+        b2 = lt ? b1 : fminf(b2, sc);
+        j1 = lt ? j + u : j1;
+        b1 = lt ? sc : b1;
+      }
+    }
+    for (; j < nm; j++) {
+      const float4 m4 = model32[j];
+      const float sc = __builtin_fmaf(-q0, m4.x, __builtin_fmaf(-q1, m4.y, __builtin_fmaf(-q2, m4.z, m4.w)));
+      const bool lt = sc < b1;
+      b2 = lt ? b1 : fminf(b2, sc);
+      j1 = lt ? j : j1;
+      b1 = lt ? sc : b1;
+    }
+    int order = j1;
+    if (!(b2 > b1 + tol2)) {
+      // more than one candidate within the bound (or non-finite values): exact binary64 among the candidates, in
+      // index order, strict `<` -- FindClosestPointSet's rule (the C# seeds with model[0] and replaces on `<`, so
+      // the lowest index among the exact minima wins; every exact minimum is a candidate by the bound)
+      const float lim = b1 + tol2;
+      double best = INFINITY;
+      bool have = false;
+      order = 0;
+      for (int jj = 0; jj < nm; jj++) {
+        const float4 m4 = model32[jj];
+        const float sc = __builtin_fmaf(-q0, m4.x, __builtin_fmaf(-q1, m4.y, __builtin_fmaf(-q2, m4.z, m4.w)));
+        if (sc <= lim || !(sc == sc) || !(lim == lim)) {
+          const double e0 = p[0] - model[3 * jj], e1 = p[1] - model[3 * jj + 1], e2 = p[2] - model[3 * jj + 2];
+          const double dd = e0 * e0 + e1 * e1 + e2 * e2;
+          if (!have || dd < best) {
+            best = dd;
+            order = jj;
+            have = true;
+          }
+        }
       }
     }
     if (nn) nn[i] = order;
@@ -90,75 +176,60 @@ __global__ __launch_bounds__(ITPB) void k_icp_pass(const double* __restrict__ mo
   }
 }
 
-// fixed-order reduction of the block partials: thread t adds blocks t, t+256, ... in order, then a fixed
-// shuffle/LDS tree over the 256 threads (same order every run -> bitwise reproducible sums)
-__global__ __launch_bounds__(ITPB) void k_icp_final(const double* __restrict__ partial, int nb, double* __restrict__ out) {
-  double s[16];
+// ---- Horn's unit-quaternion closed form (host and device: same code, same rounding) -----------------
+// cyclic Jacobi sweeps on a symmetric 4x4 (independent of the oracle's max-pivot variant).  Every index is a
+// compile-time constant after unrolling, so on the device A and V live in registers (dynamic indexing would put
+// them in scratch memory and make the single solving thread several times slower).
+template <int P, int Q>
+__host__ __device__ inline void jrot(double (&A)[4][4], double (&V)[4][4]) {
+  if (A[P][Q] == 0.0) return;
+  const double theta = (A[Q][Q] - A[P][P]) / (2.0 * A[P][Q]);
+  const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+  const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
 #pragma unroll
-  for (int k = 0; k < 16; k++) s[k] = 0.0;
-  for (int b = threadIdx.x; b < nb; b += ITPB) {
-    const double2* row = reinterpret_cast<const double2*>(partial + (size_t)b * 16);
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      double2 v = row[k];
-      s[2 * k] += v.x;
-      s[2 * k + 1] += v.y;
-    }
+  for (int k = 0; k < 4; k++) {
+    const double akp = A[k][P], akq = A[k][Q];
+    A[k][P] = c * akp - s * akq;
+    A[k][Q] = s * akp + c * akq;
   }
-  __shared__ double sm[ITPB / 64][16];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    double v = wave_sum(s[k]);
-    if (lane == 0) sm[w][k] = v;
+  for (int k = 0; k < 4; k++) {
+    const double apk = A[P][k], aqk = A[Q][k];
+    A[P][k] = c * apk - s * aqk;
+    A[Q][k] = s * apk + c * aqk;
   }
-  __syncthreads();
-  if (threadIdx.x < 16) {
-    double v = sm[0][threadIdx.x];
 #pragma unroll
-    for (int k = 1; k < ITPB / 64; k++) v += sm[k][threadIdx.x];
-    out[threadIdx.x] = v;
+  for (int k = 0; k < 4; k++) {
+    const double vkp = V[k][P], vkq = V[k][Q];
+    V[k][P] = c * vkp - s * vkq;
+    V[k][Q] = s * vkp + c * vkq;
   }
 }
 
-// ---- host: Horn's unit-quaternion closed form ---------------------------------------------------
-// cyclic Jacobi sweeps on a symmetric 4x4 (independent of the oracle's max-pivot variant)
-void jacobi4(double A[4][4], double V[4][4]) {
+__host__ __device__ inline void jacobi4(double (&A)[4][4], double (&V)[4][4]) {
+#pragma unroll
   for (int i = 0; i < 4; i++)
+#pragma unroll
     for (int j = 0; j < 4; j++) V[i][j] = i == j ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 60; sweep++) {
     double off = 0.0, diag = 0.0;
+#pragma unroll
     for (int i = 0; i < 4; i++) {
       diag += A[i][i] * A[i][i];
+#pragma unroll
       for (int j = i + 1; j < 4; j++) off += A[i][j] * A[i][j];
     }
     if (off <= 1e-34 * (diag + off) || off == 0.0) break;
-    for (int p = 0; p < 3; p++)
-      for (int q = p + 1; q < 4; q++) {
-        if (A[p][q] == 0.0) continue;
-        double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-        double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < 4; k++) {
-          double akp = A[k][p], akq = A[k][q];
-          A[k][p] = c * akp - s * akq;
-          A[k][q] = s * akp + c * akq;
-        }
-        for (int k = 0; k < 4; k++) {
-          double apk = A[p][k], aqk = A[q][k];
-          A[p][k] = c * apk - s * aqk;
-          A[q][k] = s * apk + c * aqk;
-        }
-        for (int k = 0; k < 4; k++) {
-          double vkp = V[k][p], vkq = V[k][q];
-          V[k][p] = c * vkp - s * vkq;
-          V[k][q] = s * vkp + c * vkq;
-        }
-      }
+    jrot<0, 1>(A, V);
+    jrot<0, 2>(A, V);
+    jrot<0, 3>(A, V);
+    jrot<1, 2>(A, V);
+    jrot<1, 3>(A, V);
+    jrot<2, 3>(A, V);
   }
 }
 
-bool horn(const double s[16], int64_t nd, double R1[9], double T1[3]) {
+__host__ __device__ inline bool horn(const double s[16], long long nd, double R1[9], double T1[3]) {
   const double N = (double)nd;
   double muP[3], muY[3], m[3][3];
   for (int a = 0; a < 3; a++) {
@@ -176,12 +247,18 @@ bool horn(const double s[16], int64_t nd, double R1[9], double T1[3]) {
     for (int j = 0; j < 3; j++) Q[i + 1][j + 1] = m[i][j] + m[j][i] - (i == j ? tr : 0.0);
   }
   jacobi4(Q, V);
-  int best = 0;
+  // eigenvector of the largest eigenvalue, picked without dynamic indexing (first maximum wins)
+  double ev = Q[0][0];
+  double q[4] = {V[0][0], V[1][0], V[2][0], V[3][0]};
+#pragma unroll
   for (int i = 1; i < 4; i++)
-    if (Q[i][i] > Q[best][best]) best = i;
-  double q[4] = {V[0][best], V[1][best], V[2][best], V[3][best]};
-  const double nrm = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  if (!(nrm > 0.0) || !std::isfinite(nrm)) return false;
+    if (Q[i][i] > ev) {
+      ev = Q[i][i];
+#pragma unroll
+      for (int k = 0; k < 4; k++) q[k] = V[k][i];
+    }
+  const double nrm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (!(nrm > 0.0) || !(nrm <= 1.7976931348623157e308)) return false;
   for (int i = 0; i < 4; i++) q[i] /= nrm;
   // CalculateRotation, BaseClass/ICP.cs:274-285
   R1[0] = q[0] * q[0] + q[1] * q[1] - q[2] * q[2] - q[3] * q[3];
@@ -198,25 +275,126 @@ bool horn(const double s[16], int64_t nd, double R1[9], double T1[3]) {
   return true;
 }
 
-int icp_pass(vcp_ctx* ctx, const double* d_model, int64_t nm, const double* d_data, int64_t nd, const Xf& xf,
-             double sums[16], int32_t* d_nn) {
-  hipStream_t st = ctx->stream;
-  int nb = (int)vcp_blocks(nd, ITPB, ICP_MAX_BLOCKS);
-  VCP_TRY(vcp_ensure(ctx, ctx->b_icp_part, (size_t)(ICP_MAX_BLOCKS + 1) * 16 * sizeof(double)));
-  double* part = ctx->b_icp_part.as<double>();
-  double* out = part + (size_t)ICP_MAX_BLOCKS * 16;
-  hipLaunchKernelGGL(k_icp_pass, dim3(nb), dim3(ITPB), 0, st, d_model, (int)nm, d_data, nd, xf, part, d_nn);
-  hipLaunchKernelGGL(k_icp_final, dim3(1), dim3(ITPB), 0, st, part, nb, out);
-  double* h = reinterpret_cast<double*>(ctx->pinned);
-  VCP_HIP(ctx, hipMemcpyAsync(h, out, 16 * sizeof(double), hipMemcpyDeviceToHost, st));
-  VCP_HIP(ctx, hipStreamSynchronize(st));
-  std::memcpy(sums, h, 16 * sizeof(double));
-  return VCP_OK;
+// fixed-order reduction of the partial rows (thread t adds rows t, t+256, ... in order, then a fixed shuffle/LDS
+// tree), then thread 0 advances the ICP state by one round
+__global__ __launch_bounds__(ITPB) void k_icp_step(const double* __restrict__ partial, int nb, IcpState* __restrict__ st,
+                                                  long long nd, double tol, int stop_rule, int max_iter, int mode) {
+  if (st->done) return;
+  double s[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) s[k] = 0.0;
+  for (int b = threadIdx.x; b < nb; b += ITPB) {
+    const double2* row = reinterpret_cast<const double2*>(partial + (size_t)b * 16);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      double2 v = row[k];
+      s[2 * k] += v.x;
+      s[2 * k + 1] += v.y;
+    }
+  }
+  __shared__ double sm[ITPB / 64][16];
+  __shared__ double tot[16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    double v = wave_sum(s[k]);
+    if (lane == 0) sm[w][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    double v = sm[0][threadIdx.x];
+#pragma unroll
+    for (int k = 1; k < ITPB / 64; k++) v += sm[k][threadIdx.x];
+    tot[threadIdx.x] = v;
+    st->sums[threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  if (mode == MODE_SUMS_ONLY) {
+    st->done = 1;
+    return;
+  }
+  double S[16];
+  for (int k = 0; k < 16; k++) S[k] = tot[k];
+  double R1[9], T1[3];
+  const bool ok = horn(S, nd, R1, T1);
+  const double pre_d = st->d;
+  const double d = S[15];
+  st->pre_d = pre_d;
+  st->d = d;
+  const int round = st->round + 1;
+  st->round = round;
+  bool go;
+  if (mode == MODE_VTK) go = true;  // fixed number of rounds, mean-distance check off (FrmMain.cs:855-858)
+  else if (stop_rule == VCP_STOP_RMSE) go = sqrt(d / (double)nd) >= tol;
+  else go = fabs(d - pre_d) >= tol;  // BaseClass/ICP.cs:149,180
+  if (go) {
+    if (!ok) {
+      st->failed = 1;
+      st->done = 1;
+      return;
+    }
+    if (mode == MODE_REFERENCE && round == 1) {  // :151-162 the first result overwrites R, T
+      for (int k = 0; k < 9; k++) st->R[k] = R1[k];
+      for (int k = 0; k < 3; k++) st->T[k] = T1[k];
+    } else {  // :163-177  R <- R1 R, T <- R1 T + T1
+      double tR[9], tT[3];
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+          double acc = 0.0;
+          for (int k = 0; k < 3; k++) acc += R1[3 * i + k] * st->R[3 * k + j];
+          tR[3 * i + j] = acc;
+        }
+      for (int i = 0; i < 3; i++) {
+        double acc = 0.0;
+        for (int k = 0; k < 3; k++) acc += R1[3 * i + k] * st->T[k];
+        tT[i] = acc + T1[i];
+      }
+      for (int k = 0; k < 9; k++) st->R[k] = tR[k];
+      for (int k = 0; k < 3; k++) st->T[k] = tT[k];
+    }
+  }
+  if (!go || round >= max_iter) st->done = 1;
 }
 
-void identity(Xf& xf) {
-  for (int i = 0; i < 9; i++) xf.R[i] = (i % 4 == 0) ? 1.0 : 0.0;
-  xf.T[0] = xf.T[1] = xf.T[2] = 0.0;
+void identity(IcpState& s) {
+  std::memset(&s, 0, sizeof(s));
+  s.R[0] = s.R[4] = s.R[8] = 1.0;
+}
+
+// Runs rounds on device-resident model/data until the state says done.  `init` carries the starting R,T.
+int icp_run(vcp_ctx* ctx, const double* d_model, int64_t nm, const double* d_data, int64_t nd, const IcpState& init,
+            double tol, int stop_rule, int max_iter, int mode, IcpState* out, int32_t* d_nn) {
+  hipStream_t st = ctx->stream;
+  const int nb = (int)vcp_blocks(nd, ITPB, ICP_MAX_BLOCKS);
+  VCP_TRY(vcp_ensure(ctx, ctx->b_icp_part, (size_t)ICP_MAX_BLOCKS * 16 * sizeof(double) + sizeof(IcpState) + 256));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_aux0, (size_t)nm * sizeof(float4) + 64));
+  double* part = ctx->b_icp_part.as<double>();
+  IcpState* d_st = reinterpret_cast<IcpState*>(part + (size_t)ICP_MAX_BLOCKS * 16);
+  float4* model32 = ctx->b_aux0.as<float4>();
+  IcpState* h_st = reinterpret_cast<IcpState*>(ctx->pinned);
+  *h_st = init;
+  VCP_HIP(ctx, hipMemcpyAsync(d_st, h_st, sizeof(IcpState), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_absmax, dim3(vcp_blocks(nd * 3, ITPB, 512)), dim3(ITPB), 0, st, d_data, nd * 3, &d_st->dmax);
+  hipLaunchKernelGGL(k_absmax, dim3(vcp_blocks(nm * 3, ITPB, 64)), dim3(ITPB), 0, st, d_model, nm * 3, &d_st->mmax);
+  hipLaunchKernelGGL(k_model32, dim3(vcp_blocks(nm, ITPB)), dim3(ITPB), 0, st, d_model, nm, model32);
+  int launched = 0;
+  for (;;) {
+    const int batch = mode == MODE_SUMS_ONLY ? 1 : std::min(ICP_BATCH, max_iter - launched);
+    for (int b = 0; b < batch; b++) {
+      hipLaunchKernelGGL(k_icp_pass, dim3(nb), dim3(ITPB), 0, st, d_model, model32, (int)nm, d_data, nd, d_st, part, d_nn);
+      hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(ITPB), 0, st, part, nb, d_st, (long long)nd, tol, stop_rule, max_iter,
+                         mode);
+    }
+    launched += batch;
+    VCP_HIP(ctx, hipGetLastError());
+    VCP_HIP(ctx, hipMemcpyAsync(h_st, d_st, sizeof(IcpState), hipMemcpyDeviceToHost, st));
+    VCP_HIP(ctx, hipStreamSynchronize(st));
+    if (h_st->done || launched >= max_iter || mode == MODE_SUMS_ONLY) break;
+  }
+  *out = *h_st;
+  if (out->failed) return vcp_fail(ctx, VCP_ERR_ARG, "Horn solve failed (non-finite sums)");
+  return VCP_OK;
 }
 
 }  // namespace
@@ -229,60 +407,33 @@ int vcp_icp_dev(vcp_ctx* ctx, const double* d_model, int64_t nm, const double* d
   if (!ctx) return VCP_ERR_ARG;
   if (nm <= 0) return vcp_fail(ctx, VCP_ERR_EMPTY, "empty model (model[0], BaseClass/ICP.cs:233)");
   if (nd < 0 || max_iter < 1 || !R || !T) return vcp_fail(ctx, VCP_ERR_ARG, "bad argument");
-  if (nm >= 0x7FFFFFFFLL || nd >= ((int64_t)1 << 40)) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "too many points");
+  if (nm >= 0x7FFFFFFFLL / 3 || nd >= ((int64_t)1 << 40)) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "too many points");
   if (stop_rule != VCP_STOP_SSE_DELTA && stop_rule != VCP_STOP_RMSE) return vcp_fail(ctx, VCP_ERR_ARG, "stop_rule");
   VCP_TRY(vcp_bind(ctx));
   vcp_phase_reset(ctx);
+  if (nd == 0) {  // the C# divides by zero: NaN sums, |NaN - 0| >= e is false, one round, R and T untouched
+    if (sse_o) *sse_o = 0.0;
+    if (rmse_o) *rmse_o = 0.0;
+    if (iters_o) *iters_o = 1;
+    ctx->last_timing.clear();
+    return VCP_OK;
+  }
   vcp_phase(ctx, "icp_rounds");
-  Xf xf;
-  identity(xf);  // round 1 matches the raw data (P = copy of data, :22); 1*x + 0*y + 0*z is exact
-  double pre_d = 0.0, d = 0.0;
-  int round = 0;
-  bool go;
-  do {
-    pre_d = d;
-    double s[16] = {0};
-    double R1[9], T1[3];
-    bool ok = true;
-    if (nd > 0) {
-      VCP_TRY(icp_pass(ctx, d_model, nm, d_data, nd, xf, s, nullptr));
-      ok = horn(s, nd, R1, T1);
-    }
-    d = s[15];
-    round++;
-    if (stop_rule == VCP_STOP_RMSE)
-      go = nd > 0 && std::sqrt(d / (double)nd) >= tol;
-    else
-      go = std::fabs(d - pre_d) >= tol;  // BaseClass/ICP.cs:149,180
-    if (go && nd > 0) {
-      if (!ok) return vcp_fail(ctx, VCP_ERR_ARG, "Horn solve failed (non-finite sums)");
-      if (round == 1) {
-        std::memcpy(R, R1, sizeof(R1));
-        std::memcpy(T, T1, sizeof(T1));
-      } else {
-        double tR[9], tT[3];
-        for (int i = 0; i < 3; i++)
-          for (int j = 0; j < 3; j++) {
-            double acc = 0.0;
-            for (int k = 0; k < 3; k++) acc += R1[3 * i + k] * R[3 * k + j];  // R1 * R, :167
-            tR[3 * i + j] = acc;
-          }
-        for (int i = 0; i < 3; i++) {
-          double acc = 0.0;
-          for (int k = 0; k < 3; k++) acc += R1[3 * i + k] * T[k];  // R1 * T, :168
-          tT[i] = acc + T1[i];
-        }
-        std::memcpy(R, tR, sizeof(tR));
-        std::memcpy(T, tT, sizeof(tT));
-      }
-      std::memcpy(xf.R, R, sizeof(xf.R));
-      std::memcpy(xf.T, T, sizeof(xf.T));
-    }
-  } while (go && round < max_iter);
+  IcpState init, fin;
+  identity(init);  // round 1 matches the raw data (P = copy of data, :22); 1*x + 0*y + 0*z is exact
+  VCP_TRY(icp_run(ctx, d_model, nm, d_data, nd, init, tol, stop_rule, max_iter, MODE_REFERENCE, &fin, nullptr));
   VCP_TRY(vcp_phase_finish(ctx));
-  if (sse_o) *sse_o = d;
-  if (rmse_o) *rmse_o = nd > 0 ? std::sqrt(d / (double)nd) : 0.0;
-  if (iters_o) *iters_o = round;
+  // R, T are written once some round has asked to continue (:149-162); if round 1 already stops they stay
+  // whatever the caller passed in
+  const bool wrote = fin.round > 1 || (stop_rule == VCP_STOP_RMSE ? std::sqrt(fin.d / (double)nd) >= tol
+                                                                    : std::fabs(fin.d) >= tol);
+  if (wrote) {
+    std::memcpy(R, fin.R, sizeof(fin.R));
+    std::memcpy(T, fin.T, sizeof(fin.T));
+  }
+  if (sse_o) *sse_o = fin.d;
+  if (rmse_o) *rmse_o = std::sqrt(fin.d / (double)nd);
+  if (iters_o) *iters_o = fin.round;
   return VCP_OK;
 }
 
@@ -312,7 +463,7 @@ int vcp_icp_vtklike(vcp_ctx* ctx, const double* source, int64_t ns, const double
   if (!ctx) return VCP_ERR_ARG;
   if (ns <= 0 || nt <= 0) return vcp_fail(ctx, VCP_ERR_EMPTY, "empty source or target");
   if (max_iter < 1 || max_landmarks < 1 || !source || !target || !M) return vcp_fail(ctx, VCP_ERR_ARG, "bad argument");
-  if (nt >= 0x7FFFFFFFLL) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "target too large");
+  if (nt >= 0x7FFFFFFFLL / 3) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "target too large");
   VCP_TRY(vcp_bind(ctx));
   vcp_phase_reset(ctx);
   int64_t step = 1;
@@ -321,52 +472,31 @@ int vcp_icp_vtklike(vcp_ctx* ctx, const double* source, int64_t ns, const double
   std::vector<double> a((size_t)3 * nb);
   for (int64_t i = 0, j = 0; i < nb; i++, j += step)
     for (int c = 0; c < 3; c++) a[3 * i + c] = source[3 * j + c];
-  Xf xf;
-  identity(xf);
+  IcpState init, fin;
+  identity(init);
   if (start_by_matching_centroids) {  // sequential binary64 means over ALL points of both sets
     double cs[3] = {0, 0, 0}, ct[3] = {0, 0, 0};
     for (int64_t i = 0; i < ns; i++)
       for (int c = 0; c < 3; c++) cs[c] += source[3 * i + c];
     for (int64_t i = 0; i < nt; i++)
       for (int c = 0; c < 3; c++) ct[c] += target[3 * i + c];
-    for (int c = 0; c < 3; c++) xf.T[c] = ct[c] / (double)nt - cs[c] / (double)ns;
+    for (int c = 0; c < 3; c++) init.T[c] = ct[c] / (double)nt - cs[c] / (double)ns;
   }
   VCP_TRY(vcp_ensure(ctx, ctx->b_in0, (size_t)nt * 24));
   VCP_TRY(vcp_ensure(ctx, ctx->b_in2, (size_t)nb * 24));
   VCP_HIP(ctx, hipMemcpyAsync(ctx->b_in0.p, target, (size_t)nt * 24, hipMemcpyHostToDevice, ctx->stream));
   VCP_HIP(ctx, hipMemcpyAsync(ctx->b_in2.p, a.data(), (size_t)nb * 24, hipMemcpyHostToDevice, ctx->stream));
-  int it = 0;
-  double md = 0;
-  for (;;) {
-    double s[16], R1[9], T1[3];
-    VCP_TRY(icp_pass(ctx, ctx->b_in0.as<double>(), nt, ctx->b_in2.as<double>(), nb, xf, s, nullptr));
-    if (!horn(s, nb, R1, T1)) return vcp_fail(ctx, VCP_ERR_ARG, "Horn solve failed (non-finite sums)");
-    double tR[9], tT[3];
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 3; j++) {
-        double acc = 0.0;
-        for (int k = 0; k < 3; k++) acc += R1[3 * i + k] * xf.R[3 * k + j];
-        tR[3 * i + j] = acc;
-      }
-    for (int i = 0; i < 3; i++) {
-      double acc = 0.0;
-      for (int k = 0; k < 3; k++) acc += R1[3 * i + k] * xf.T[k];
-      tT[i] = acc + T1[i];
-    }
-    std::memcpy(xf.R, tR, sizeof(tR));
-    std::memcpy(xf.T, tT, sizeof(tT));
-    md = std::sqrt(s[15] / (double)nb);
-    it++;
-    if (it >= max_iter) break;
-  }
+  VCP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `a` is a local buffer
+  VCP_TRY(icp_run(ctx, ctx->b_in0.as<double>(), nt, ctx->b_in2.as<double>(), nb, init, 0.0, VCP_STOP_SSE_DELTA, max_iter,
+                  MODE_VTK, &fin, nullptr));
   for (int r = 0; r < 3; r++) {
-    for (int c = 0; c < 3; c++) M[4 * r + c] = xf.R[3 * r + c];
-    M[4 * r + 3] = xf.T[r];
+    for (int c = 0; c < 3; c++) M[4 * r + c] = fin.R[3 * r + c];
+    M[4 * r + 3] = fin.T[r];
   }
   M[12] = M[13] = M[14] = 0;
   M[15] = 1;
-  if (mean_dist) *mean_dist = md;
-  if (iters_o) *iters_o = it;
+  if (mean_dist) *mean_dist = std::sqrt(fin.d / (double)nb);
+  if (iters_o) *iters_o = fin.round;
   return VCP_OK;
 }
 
@@ -375,7 +505,7 @@ int vcp_icp_sums(vcp_ctx* ctx, const double* model, int64_t nm, const double* da
   if (!ctx) return VCP_ERR_ARG;
   if (nm <= 0) return vcp_fail(ctx, VCP_ERR_EMPTY, "empty model");
   if (nd <= 0 || !model || !data || !sums) return vcp_fail(ctx, VCP_ERR_ARG, "bad argument");
-  if (nm >= 0x7FFFFFFFLL) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "model too large");
+  if (nm >= 0x7FFFFFFFLL / 3) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "model too large");
   VCP_TRY(vcp_bind(ctx));
   vcp_phase_reset(ctx);
   VCP_TRY(vcp_ensure(ctx, ctx->b_in0, (size_t)nm * 24));
@@ -383,12 +513,13 @@ int vcp_icp_sums(vcp_ctx* ctx, const double* model, int64_t nm, const double* da
   VCP_TRY(vcp_ensure(ctx, ctx->b_out0, (size_t)nd * 4));
   VCP_HIP(ctx, hipMemcpyAsync(ctx->b_in0.p, model, (size_t)nm * 24, hipMemcpyHostToDevice, ctx->stream));
   VCP_HIP(ctx, hipMemcpyAsync(ctx->b_in2.p, data, (size_t)nd * 24, hipMemcpyHostToDevice, ctx->stream));
-  Xf xf;
-  identity(xf);
-  if (R) std::memcpy(xf.R, R, sizeof(xf.R));
-  if (T) std::memcpy(xf.T, T, sizeof(xf.T));
-  VCP_TRY(icp_pass(ctx, ctx->b_in0.as<double>(), nm, ctx->b_in2.as<double>(), nd, xf, sums,
-                   nn ? ctx->b_out0.as<int32_t>() : nullptr));
+  IcpState init, fin;
+  identity(init);
+  if (R) std::memcpy(init.R, R, sizeof(init.R));
+  if (T) std::memcpy(init.T, T, sizeof(init.T));
+  VCP_TRY(icp_run(ctx, ctx->b_in0.as<double>(), nm, ctx->b_in2.as<double>(), nd, init, 0.0, VCP_STOP_SSE_DELTA, 1,
+                  MODE_SUMS_ONLY, &fin, nn ? ctx->b_out0.as<int32_t>() : nullptr));
+  std::memcpy(sums, fin.sums, sizeof(fin.sums));
   if (nn) {
     VCP_HIP(ctx, hipMemcpyAsync(nn, ctx->b_out0.p, (size_t)nd * 4, hipMemcpyDeviceToHost, ctx->stream));
     VCP_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -19,10 +19,13 @@ from collections import defaultdict
 
 PHASE_OF = {
     "k_bounds": "bounds", "k_bounds_final": "bounds", "k_cell_hist": "cell_hist", "k_scatter": "scatter",
-    "k_core": "core_count", "k_union": "union", "k_init_parent": "union", "k_flatten": "flatten_number",
-    "k_seedflag": "flatten_number", "k_rootid": "flatten_number", "k_rootk": "flatten_number", "k_label": "label",
+    "k_scan_tile_sums": "cell_scan", "k_scan_offsets": "cell_scan", "k_scan_tiles": "cell_scan",
+    "k_core": "core_count", "k_wl_fill": "core_count",
+    "k_union": "union", "k_union_init": "union", "k_flatten0": "union", "k_init_parent": "union",
+    "k_flatten": "flatten_number", "k_seed_popc": "flatten_number", "k_seedflag": "flatten_number",
+    "k_rootk": "flatten_number", "k_labk_rest": "flatten_number",
     "k_border": "border", "k_output": "output",
-    "k_icp_pass": "icp", "k_icp_final": "icp",
+    "k_icp_pass": "icp", "k_icp_step": "icp", "k_model32": "icp", "k_absmax": "icp",
 }
 
 

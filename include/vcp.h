@@ -143,6 +143,35 @@ int vcp_blocks_finish_dev(vcp_ctx* ctx, const int32_t* d_local, int64_t evals_bl
                           int64_t* m_out, int32_t* kept, int32_t* del_sum, int32_t* cluster_amount,
                           int64_t* dist_evals);
 
+/* -- exact DBSCAN over several GPUs (SURVEY.md 8e mode 2) -----------------------------------
+ * One monolithic DBImproved.dbscan (BC/DBImproved.cs:91-114) over a cloud that is spread over several
+ * ranks (one process and one context per GPU): every rank clusters its own points plus a 2*eps halo of
+ * the other ranks' points, the ranks agree on the components that cross a boundary, and each labels its
+ * own points with the ids the single-GPU call would have produced (vtkcloudpoint_amd/distributed.py:
+ * exact_slabs drives the exchange over RCCL).
+ *   begin    d_coords [n*dim] = own points followed by halo points; d_ord [n] = position of each point in
+ *            the GLOBAL list (what "index in lst" means for the seed / numbering rules); d_noexpand [n]
+ *            (may be NULL) = 1 for points whose neighbourhood is incomplete here: they count as
+ *            neighbours but never seed or extend a cluster.  Builds the grid, the core flags and the
+ *            LOCAL components; writes d_rep [n] = smallest ord of the point's local component
+ *            (0xFFFFFFFF for points that are not expanding) and d_is_core [n] (may be NULL);
+ *            *n_comp = number of local components.
+ *   comps    copies the n_comp component seeds (their smallest ord, in no particular order) to the host.
+ *   finish   map_rep [n_comp] strictly ascending = the component seeds; map_k [n_comp] = index of the
+ *            component's GLOBAL cluster in the table tab_gid / tab_seed [n_tab] (cluster id, strictly
+ *            ascending, and the global seed position of that cluster); all four are host arrays.  Applies
+ *            the border rule (:87, largest adjacent id) and writes d_labels [n], d_is_classed [n] (may be
+ *            NULL); *twice = own points (own_lo <= ord < own_lo + own_count) that the C# loop queries a
+ *            second time (the iritatorNum term).
+ * The state lives in the context's workspace: no other call on this context between begin and finish. */
+int vcp_slab_begin(vcp_ctx* ctx, const double* d_coords, int64_t n, int dim, int metric, double eps,
+                   int min_pts, const uint8_t* d_noexpand, const uint32_t* d_ord, uint32_t* d_rep,
+                   uint8_t* d_is_core, int64_t* n_comp);
+int vcp_slab_comps(vcp_ctx* ctx, uint32_t* comp_rep);
+int vcp_slab_finish(vcp_ctx* ctx, const uint32_t* map_rep, const uint32_t* map_k, int64_t n_tab,
+                    const int32_t* tab_gid, const uint32_t* tab_seed, uint32_t own_lo, uint32_t own_count,
+                    int32_t* d_labels, uint8_t* d_is_classed, int64_t* twice);
+
 /* -- centroids ----------------------------------------------------------------------------
  * Replaces Tools.GetClusList (BC/Tools.cs:162-195; also getClusterCenter :118-155): per cluster
  * id 1..K the mean of (X,Y,Z) -> c3 [K*3] and of (motor_x,motor_y) -> c2 [K*2]; counts [K].

@@ -369,3 +369,53 @@ class StagedBlocks:
                                     C.byref(dels), C.byref(ca), C.byref(ev)))
         return dict(m=m.value, kept=kept.value, del_sum=dels.value, cluster_amount=ca.value, evals=ev.value,
                     order=order[: m.value].copy())
+
+
+class StagedSlab:
+    """The oracle's staged exact-global DBSCAN with the method names of the product's Context (slab_begin /
+    slab_comps / slab_finish), so that distributed.exact_slabs can be exercised on CPU tensors (gloo) in the
+    tests.  Pointers are host addresses here."""
+
+    def __init__(self):
+        self.s = None
+
+    @staticmethod
+    def _view(ptr, ctype, dtype, shape):
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=shape).view(dtype)
+
+    def slab_begin(self, d_coords, n, dim, metric, eps, min_pts, d_noexpand, d_ord, d_rep, d_is_core=None):
+        coords = self._view(d_coords, C.c_double, np.float64, (n * dim,)).copy()
+        noexp = None if not d_noexpand else self._view(d_noexpand, C.c_uint8, np.uint8, (n,)).copy()
+        ord_ = self._view(d_ord, C.c_uint32, np.uint32, (n,)).copy()
+        rep = self._view(d_rep, C.c_uint32, np.uint32, (n,))
+        core = None if not d_is_core else self._view(d_is_core, C.c_uint8, np.uint8, (n,))
+        nc = C.c_int64(0)
+        _chk(lib().orc_slab_begin(_p(coords, C.c_double), C.c_int64(n), int(dim), int(metric), C.c_double(eps),
+                                  int(min_pts), None if noexp is None else _p(noexp, C.c_uint8), _p(ord_, C.c_uint32),
+                                  _p(rep, C.c_uint32), None if core is None else _p(core, C.c_uint8), C.byref(nc)))
+        self.s = dict(coords=coords, n=n, dim=dim, metric=int(metric), eps=float(eps), noexp=noexp, ord=ord_,
+                      rep=rep.copy(), n_comp=nc.value)
+        return nc.value
+
+    def slab_comps(self):
+        rep = self.s["rep"]
+        return np.unique(rep[rep != 0xFFFFFFFF]).astype(np.uint32)
+
+    def slab_finish(self, map_rep, map_k, tab_gid, tab_seed, own_lo, own_count, d_labels, d_is_classed=None):
+        s = self.s
+        n = s["n"]
+        map_rep = np.ascontiguousarray(map_rep, np.uint32)
+        map_k = np.ascontiguousarray(map_k, np.uint32)
+        tab_gid = np.ascontiguousarray(tab_gid, np.int32)
+        tab_seed = np.ascontiguousarray(tab_seed, np.uint32)
+        labels = self._view(d_labels, C.c_int32, np.int32, (n,))
+        classed = None if not d_is_classed else self._view(d_is_classed, C.c_uint8, np.uint8, (n,))
+        tw = C.c_int64(0)
+        _chk(lib().orc_slab_finish(_p(s["coords"], C.c_double), C.c_int64(n), s["dim"], s["metric"],
+                                   C.c_double(s["eps"]), None if s["noexp"] is None else _p(s["noexp"], C.c_uint8),
+                                   _p(s["ord"], C.c_uint32), _p(s["rep"], C.c_uint32), _p(map_rep, C.c_uint32),
+                                   _p(map_k, C.c_uint32), C.c_int64(len(map_rep)), _p(tab_gid, C.c_int32),
+                                   _p(tab_seed, C.c_uint32), C.c_int64(len(tab_gid)), C.c_uint32(own_lo),
+                                   C.c_uint32(own_count), _p(labels, C.c_int32),
+                                   None if classed is None else _p(classed, C.c_uint8), C.byref(tw)))
+        return tw.value

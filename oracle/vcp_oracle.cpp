@@ -390,6 +390,94 @@ int orc_dbscan_canonical(const double* coords, int64_t n, int dim, int metric, d
                                cf_out, dist_evals);
 }
 
+// -------------------------------------------------------------------------------------
+// Staged form of the canonical formulation for a cloud spread over several ranks (SURVEY.md 8e mode 2):
+// the same three facts of BC/DBImproved.cs as dbscan_canonical_impl -- core test :33-54, transitive
+// expansion :56-90, border rule :87 -- with "index in the list" replaced by the caller's global position
+// `ord`, and cluster numbers supplied by the caller once all ranks have agreed on them.
+int orc_slab_begin(const double* coords, int64_t n, int dim, int metric, double eps, int min_pts,
+                   const uint8_t* noexpand, const uint32_t* ord, uint32_t* rep, uint8_t* is_core,
+                   int64_t* n_comp) {
+  if (n <= 0 || !metric_ok(metric, dim) || metric == ORC_SIGNED_SUM_2D || !(eps >= 0.0)) return ORC_ERR_ARG;
+  Dist d{coords, dim, metric};
+  Grid g;
+  g.build(coords, n, dim, metric == ORC_L2_3D ? 3 : 2, eps);
+  std::vector<uint8_t> expanding(n, 0);
+  for (int64_t i = 0; i < n; i++) {
+    int64_t cnt = 0;
+    g.for_candidates(i, [&](int64_t j) {
+      if (d(i, j) <= eps) cnt++;
+    });
+    const bool core = cnt >= (int64_t)min_pts;
+    if (is_core) is_core[i] = core;
+    expanding[i] = core && !(noexpand && noexpand[i]);
+  }
+  UF uf(n);
+  for (int64_t i = 0; i < n; i++) {
+    if (!expanding[i]) continue;
+    g.for_candidates(i, [&](int64_t j) {
+      if (j < i && expanding[j] && d(i, j) <= eps) uf.unite(i, j);
+    });
+  }
+  std::vector<uint32_t> mn(n, 0xFFFFFFFFu);
+  for (int64_t i = 0; i < n; i++)
+    if (expanding[i]) {
+      int64_t r = uf.find(i);
+      mn[r] = std::min(mn[r], ord[i]);
+    }
+  int64_t comps = 0;
+  for (int64_t i = 0; i < n; i++) {
+    rep[i] = expanding[i] ? mn[uf.find(i)] : 0xFFFFFFFFu;
+    if (expanding[i] && uf.find(i) == i) comps++;
+  }
+  if (n_comp) *n_comp = comps;
+  return ORC_OK;
+}
+
+int orc_slab_finish(const double* coords, int64_t n, int dim, int metric, double eps, const uint8_t* noexpand,
+                    const uint32_t* ord, const uint32_t* rep, const uint32_t* map_rep, const uint32_t* map_k,
+                    int64_t n_map, const int32_t* tab_gid, const uint32_t* tab_seed, int64_t n_tab, uint32_t own_lo,
+                    uint32_t own_count, int32_t* labels, uint8_t* is_classed, int64_t* twice) {
+  if (n <= 0 || !metric_ok(metric, dim) || metric == ORC_SIGNED_SUM_2D || !(eps >= 0.0)) return ORC_ERR_ARG;
+  Dist d{coords, dim, metric};
+  Grid g;
+  g.build(coords, n, dim, metric == ORC_L2_3D ? 3 : 2, eps);
+  auto table_index = [&](uint32_t r, int64_t* k) {
+    const uint32_t* e = map_rep + n_map;
+    const uint32_t* it = std::lower_bound(map_rep, e, r);
+    if (it == e || *it != r) return false;
+    *k = map_k[it - map_rep];
+    return *k < n_tab;
+  };
+  int64_t tw = 0;
+  for (int64_t i = 0; i < n; i++) {
+    int64_t k = 0;
+    if (rep[i] != 0xFFFFFFFFu) {
+      if (!table_index(rep[i], &k)) return ORC_ERR_ARG;
+      labels[i] = tab_gid[k];
+      if (is_classed) is_classed[i] = 1;
+      continue;
+    }
+    int64_t kmax = -1, kmin = n_tab;
+    bool bad = false;
+    g.for_candidates(i, [&](int64_t j) {
+      if (rep[j] != 0xFFFFFFFFu && d(i, j) <= eps) {
+        int64_t kj = 0;
+        if (!table_index(rep[j], &kj)) bad = true;
+        kmax = std::max(kmax, kj);
+        kmin = std::min(kmin, kj);
+      }
+    });
+    if (bad) return ORC_ERR_ARG;
+    labels[i] = kmax >= 0 ? tab_gid[kmax] : 0;  // the table is ascending in cluster id: :87, last writer = largest id
+    if (is_classed) is_classed[i] = kmax >= 0;
+    const bool own = (uint32_t)(ord[i] - own_lo) < own_count;
+    if (kmax >= 0 && own && !(noexpand && noexpand[i]) && ord[i] < tab_seed[kmin]) tw++;
+  }
+  if (twice) *twice = tw;
+  return ORC_OK;
+}
+
 int orc_db_literal(const double* coords, int64_t n, int dim, double eps, int min_pts,
                    const uint8_t* shown, uint8_t* classed, int32_t* labels, uint8_t* is_key,
                    int32_t* cluster_amount, int32_t* points_amount, int64_t* dist_evals) {

@@ -58,6 +58,19 @@ int orc_dbscan_canonical(const double* coords, int64_t n, int dim, int metric, d
                          int min_pts, int32_t cf_in, uint8_t* classed, int32_t* labels,
                          uint8_t* is_key, int32_t* cf_out, int64_t* dist_evals);
 
+/* Staged canonical formulation for a cloud spread over several ranks (SURVEY.md 8e mode 2; mirrors
+ * vcp_slab_begin / vcp_slab_finish of include/vcp.h).  begin: core flags, local components of the
+ * expanding points (core and not noexpand), rep[i] = smallest ord of the component of i or 0xFFFFFFFF.
+ * finish: labels from the caller's table of global clusters (map_rep ascending -> map_k -> tab_gid /
+ * tab_seed, tab_gid ascending), border rule BC/DBImproved.cs:87, `twice` over own points. */
+int orc_slab_begin(const double* coords, int64_t n, int dim, int metric, double eps, int min_pts,
+                   const uint8_t* noexpand, const uint32_t* ord, uint32_t* rep, uint8_t* is_core,
+                   int64_t* n_comp);
+int orc_slab_finish(const double* coords, int64_t n, int dim, int metric, double eps, const uint8_t* noexpand,
+                    const uint32_t* ord, const uint32_t* rep, const uint32_t* map_rep, const uint32_t* map_k,
+                    int64_t n_map, const int32_t* tab_gid, const uint32_t* tab_seed, int64_t n_tab, uint32_t own_lo,
+                    uint32_t own_count, int32_t* labels, uint8_t* is_classed, int64_t* twice);
+
 /* BC/DB.cs:14-115, line by line (metric dx+dy on X,Y; ifShown filter). */
 int orc_db_literal(const double* coords, int64_t n, int dim, double eps, int min_pts,
                    const uint8_t* shown, uint8_t* classed, int32_t* labels, uint8_t* is_key,

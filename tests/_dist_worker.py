@@ -1,7 +1,7 @@
 """Worker for tests/test_distributed_gloo.py: one rank of a world_size-N gloo group on CPU.  The compute
 backend is the oracle's staged block pipeline (CPU); what is under test is the distributed driver
 (vtkcloudpoint_amd/distributed.py): share ranges, padded variable-length all-gather, eval all-reduce,
-slab renumbering."""
+slab renumbering, exact-global slabs."""
 import json
 import os
 import sys
@@ -79,6 +79,19 @@ def main():
     for b in range(2):
         ok = ok and bool(np.array_equal(pipe.gathered[b].numpy(), np.concatenate(exp)))
     res["pipe_ok"] = ok
+    # 6. exact_slabs (SURVEY 8e mode 2): the cloud cut into x-slabs == one monolithic DBImproved.dbscan
+    cloud = synth.config_cloud(40_000, seed=33)["motor"]
+    cloud = cloud[np.argsort(cloud[:, 0], kind="stable")]
+    cuts = [len(cloud) * q // world for q in range(world + 1)]
+    part = torch.from_numpy(np.ascontiguousarray(cloud[cuts[rank]:cuts[rank + 1]]))
+    ex = D.exact_slabs(O.StagedSlab(), part, 0.3, 5, 0, cf_in=3)
+    mono = O.dbscan(cloud, 0.3, 5, 0, cf_in=3)
+    sl = slice(cuts[rank], cuts[rank + 1])
+    res["exact_ok"] = (bool(np.array_equal(ex["labels"].numpy(), mono["labels"][sl]))
+                       and bool(np.array_equal(ex["is_core"].numpy(), mono["is_key"][sl]))
+                       and ex["cf"] == mono["cf"] and ex["dist_evals"] == mono["evals"])
+    res["exact_halo"] = ex["halo"]
+    res["exact_clusters"] = ex["cf"] - 3
     with open("%s.%d" % (out_path, rank), "w") as f:
         json.dump(res, f)
     dist.barrier()

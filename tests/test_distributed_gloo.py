@@ -26,6 +26,7 @@ def test_sharded_blocks_and_collectives(world, port, tmp_path, oracle):
     for r, x in enumerate(res):
         assert x["blocks_labels_equal"] and x["blocks_meta_equal"], (r, x)
         assert x["varlen_ok"] and x["slab_ok"] and x["pipe_ok"]
+        assert x["exact_ok"] and x["exact_clusters"] > 10 and 0 < x["exact_halo"] < 20_000, (r, x)
         assert x["offset"] == sum(10 * (q + 1) for q in range(r))
         assert x["total"] == sum(10 * (q + 1) for q in range(world))
         assert x["sum"] == world * (world + 1) // 2

@@ -25,6 +25,7 @@ SYMBOLS = [
     "vcp_blocks_share", "vcp_blocks_cluster_dev", "vcp_blocks_finish_dev", "vcp_centroids", "vcp_centroids_dev",
     "vcp_merge_centroids", "vcp_refresh_by_dictionary", "vcp_icp", "vcp_icp_dev", "vcp_icp_sums",
     "vcp_match", "vcp_mcc", "vcp_assign_truths", "vcp_icp_vtklike", "vcp_import_convert",
+    "vcp_slab_begin", "vcp_slab_comps", "vcp_slab_finish",
 ]
 
 
@@ -290,6 +291,35 @@ class Context:
                                               _ptr(d_block_of), _ptr(d_merge_order), C.byref(m), C.byref(kept),
                                               C.byref(dels), C.byref(ca), C.byref(ev)))
         return dict(m=m.value, kept=kept.value, del_sum=dels.value, cluster_amount=ca.value, evals=ev.value)
+
+    # -- exact DBSCAN over several GPUs: staged engine (all d_* are device pointers) --------------------
+    def slab_begin(self, d_coords, n, dim, metric, eps, min_pts, d_noexpand, d_ord, d_rep, d_is_core=None):
+        """Grid, core flags and local components of own + halo points; returns the number of local components."""
+        nc = C.c_int64(0)
+        self._chk(lib().vcp_slab_begin(self._h, _ptr(d_coords), C.c_int64(n), C.c_int(dim), C.c_int(int(metric)),
+                                       C.c_double(eps), C.c_int(min_pts), _ptr(d_noexpand), _ptr(d_ord), _ptr(d_rep),
+                                       _ptr(d_is_core), C.byref(nc)))
+        self._slab_ncomp = nc.value
+        return nc.value
+
+    def slab_comps(self):
+        """Seeds (smallest global list position) of the local components, ascending."""
+        out = np.zeros(self._slab_ncomp, np.uint32)
+        self._chk(lib().vcp_slab_comps(self._h, _ptr(out)))
+        out.sort()
+        return out
+
+    def slab_finish(self, map_rep, map_k, tab_gid, tab_seed, own_lo, own_count, d_labels, d_is_classed=None):
+        """Border rule and labels from the resolved global clusters; returns the `twice` count of own points."""
+        map_rep = np.ascontiguousarray(map_rep, np.uint32)
+        map_k = np.ascontiguousarray(map_k, np.uint32)
+        tab_gid = np.ascontiguousarray(tab_gid, np.int32)
+        tab_seed = np.ascontiguousarray(tab_seed, np.uint32)
+        tw = C.c_int64(0)
+        self._chk(lib().vcp_slab_finish(self._h, _ptr(map_rep), _ptr(map_k), C.c_int64(len(tab_gid)), _ptr(tab_gid),
+                                        _ptr(tab_seed), C.c_uint32(own_lo), C.c_uint32(own_count), _ptr(d_labels),
+                                        _ptr(d_is_classed), C.byref(tw)))
+        return tw.value
 
     def mcc(self, xy, labels, K, order=None):
         """Tools.getCircles: minimal bounding circle of every cluster with more than 3 points."""

@@ -46,6 +46,21 @@ struct GridP {
   uint32_t ncells;
 };
 
+}  // namespace
+
+// what vcp_slab_comps / vcp_slab_finish need from vcp_slab_begin (everything else stays in the context's
+// workspace buffers, which nothing else touches between the two calls)
+struct SlabState {
+  bool valid = false;
+  int gd = 2, metric = 0;
+  int64_t n = 0, n_comp = 0;
+  GridP g;
+  double thr = 0.0;
+  unsigned nb = 0;
+};
+
+namespace {
+
 // linear id of cell (cx,cy,cz), x fastest: the 3 cells of a neighbour row are one contiguous position range.
 // (A tile-major order -- tiles of 4..16 cells per axis -- was measured 5-25 % SLOWER on MI355X for these
 // latency-bound search loops, with or without the XCD-aware block map, and was dropped.)
@@ -706,7 +721,8 @@ __global__ __launch_bounds__(TPB) void k_border(const double* __restrict__ sorte
                                                const uint32_t* __restrict__ parent, const uint32_t* __restrict__ sord,
                                                const uint32_t* __restrict__ rootk, const uint32_t* __restrict__ clseed,
                                                uint32_t* __restrict__ labk, unsigned long long* __restrict__ counters,
-                                               uint32_t* __restrict__ group_twice, WorkList wlB) {
+                                               uint32_t* __restrict__ group_twice, WorkList wlB, uint32_t own_lo,
+                                               uint32_t own_span) {
   const uint32_t p = wl_fetch(wlB);
   unsigned twice = 0;
   if (p != NONE) {
@@ -743,7 +759,8 @@ __global__ __launch_bounds__(TPB) void k_border(const double* __restrict__ sorte
         return true;
       });
       out = mx;
-      if (mx != 0 && !(fl & F_CLASSED) && sord[p] < clseed[mnk]) {
+      // staged (slab) calls count only the caller's own points: list positions in [own_lo, own_lo + own_span)
+      if (mx != 0 && !(fl & F_CLASSED) && sord[p] - own_lo < own_span && sord[p] < clseed[mnk]) {
         twice = 1;
         if (GROUPED) atomicAdd(&group_twice[myg], 1u);
       }
@@ -876,6 +893,96 @@ __global__ __launch_bounds__(TPB) void k_degenerate(const uint8_t* __restrict__ 
   if (is_classed) is_classed[i] = cls ? 1 : 0;  // expandCluster never marks the seed itself
 }
 
+// ---- staged (slab) calls: exact DBSCAN over several GPUs (distributed.exact_slabs) ---------------------
+// After the component build the caller needs, per point, the seed of its LOCAL component (smallest ord) and
+// the list of local components; it resolves them against the other ranks' and comes back with, per local
+// component, an index into a table of global clusters sorted by cluster id (vcp_slab_finish).
+__global__ __launch_bounds__(TPB) void k_slab_count(const uint32_t* __restrict__ parent, const uint8_t* __restrict__ flags,
+                                                   const uint32_t* __restrict__ cellstart, uint32_t ncells,
+                                                   uint32_t* __restrict__ blkcnt) {
+  const uint32_t nin = cellstart[ncells];
+  int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  const bool root = p < nin && (flags[p] & F_EXPAND) && parent[p] == (uint32_t)p;
+  __shared__ unsigned wc[TPB / 64];
+  const unsigned long long m = __ballot(root);
+  if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = (unsigned)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned a = 0;
+    for (int k = 0; k < TPB / 64; k++) a += wc[k];
+    blkcnt[blockIdx.x] = a;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_slab_fill(const uint32_t* __restrict__ parent, const uint8_t* __restrict__ flags,
+                                                  const uint32_t* __restrict__ minord,
+                                                  const uint32_t* __restrict__ cellstart, uint32_t ncells,
+                                                  const uint32_t* __restrict__ blkscan, uint32_t* __restrict__ comps) {
+  const uint32_t nin = cellstart[ncells];
+  int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  const bool root = p < nin && (flags[p] & F_EXPAND) && parent[p] == (uint32_t)p;
+  __shared__ unsigned wc[TPB / 64];
+  const unsigned long long m = __ballot(root);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) wc[w] = (unsigned)__popcll(m);
+  __syncthreads();
+  if (root) {
+    unsigned before = 0;
+    for (int k = 0; k < w; k++) before += wc[k];
+    before += (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+    comps[blkscan[blockIdx.x] + before] = minord[p];
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_slab_out(int64_t n, const uint32_t* __restrict__ pos,
+                                                 const uint8_t* __restrict__ flags, const uint32_t* __restrict__ parent,
+                                                 const uint32_t* __restrict__ minord, uint32_t* __restrict__ rep,
+                                                 uint8_t* __restrict__ is_core) {
+  int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t p = pos[i];
+  const uint8_t fl = flags[p];
+  rep[i] = (fl & F_EXPAND) ? minord[parent[p]] : NONE;
+  if (is_core) is_core[i] = (fl & F_CORE) ? 1 : 0;
+}
+
+// per root: index of its global cluster in the caller's table (binary search of the local seed)
+__global__ __launch_bounds__(TPB) void k_slab_rootk(const uint32_t* __restrict__ parent, const uint8_t* __restrict__ flags,
+                                                   const uint32_t* __restrict__ minord,
+                                                   const uint32_t* __restrict__ cellstart, uint32_t ncells,
+                                                   const uint32_t* __restrict__ map_rep, const uint32_t* __restrict__ map_k,
+                                                   uint32_t nmap, uint32_t* __restrict__ rootk,
+                                                   unsigned long long* __restrict__ missing) {
+  const uint32_t nin = cellstart[ncells];
+  int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (p >= nin) return;
+  if ((flags[p] & F_EXPAND) && parent[p] == (uint32_t)p) {
+    const uint32_t key = minord[p];
+    uint32_t lo = 0, hi = nmap;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (map_rep[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    if (lo < nmap && map_rep[lo] == key) {
+      rootk[p] = map_k[lo];
+    } else {
+      rootk[p] = 0;
+      atomicAdd(missing, 1ull);
+    }
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_slab_output(int64_t n, const uint32_t* __restrict__ pos,
+                                                    const uint32_t* __restrict__ labk, const int32_t* __restrict__ tab_gid,
+                                                    int32_t* __restrict__ labels, uint8_t* __restrict__ is_classed) {
+  int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t k1 = labk[pos[i]] >> 2;
+  const int32_t lab = k1 ? tab_gid[k1 - 1] : 0;
+  labels[i] = lab;
+  if (is_classed) is_classed[i] = lab != 0;
+}
+
 // largest binary64 s such that sqrt(s) <= eps (sqrt is correctly rounded and monotone), so that
 // `sqrt(s) <= eps` can be tested as `s <= thr` without a device sqrt.
 double l2_threshold(double eps) {
@@ -918,7 +1025,7 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   const bool all_finite = h[6] == 0.0;
 
   const double thr = (METRIC == VCP_L1_2D) ? eps : l2_threshold(eps);
-  if (!GROUPED && all_finite) {
+  if (!GROUPED && all_finite && !(ext && ext->slab)) {
     // monotone rounding: |dx| <= hi-lo on every axis, so the box measure bounds every pair's distance form
     const double wx = h[3] - h[0], wy = h[4] - h[1], wz = GD == 3 ? h[5] - h[2] : 0.0;
     const double box = METRIC == VCP_L1_2D ? std::fabs(wx) + std::fabs(wy)
@@ -1081,6 +1188,31 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   }
   vcp_phase(ctx, "flatten_number");
   hipLaunchKernelGGL(k_flatten, dim3(nb), dim3(TPB), 0, st, parent, flags, sord, minord, cellcnt, g.ncells);
+  if (!GROUPED && ext && ext->slab) {
+    // staged call: hand the local components to the caller and keep the grid state for vcp_slab_finish
+    vcp_phase(ctx, "slab_components");
+    hipLaunchKernelGGL(k_slab_count, dim3(nb), dim3(TPB), 0, st, parent, flags, cellcnt, g.ncells, blkE);
+    VCP_TRY(vcp_exclusive_scan_u32(ctx, blkE, blkE, (int64_t)nb + 1, nullptr));
+    hipLaunchKernelGGL(k_slab_fill, dim3(nb), dim3(TPB), 0, st, parent, flags, minord, cellcnt, g.ncells, blkE, clseed);
+    hipLaunchKernelGGL(k_slab_out, dim3(nb), dim3(TPB), 0, st, n, pos, flags, parent, minord, ext->d_slab_rep, d_is_core);
+    VCP_HIP(ctx, hipGetLastError());
+    uint32_t* hn = reinterpret_cast<uint32_t*>(ctx->pinned) + 64;
+    VCP_HIP(ctx, hipMemcpyAsync(hn, blkE + nb, 4, hipMemcpyDeviceToHost, st));
+    VCP_TRY(vcp_phase_finish(ctx));
+    VCP_HIP(ctx, hipStreamSynchronize(st));
+    if (!ctx->slab) ctx->slab = new SlabState();
+    SlabState& ss = *ctx->slab;
+    ss.valid = true;
+    ss.gd = GD;
+    ss.metric = METRIC;
+    ss.n = n;
+    ss.n_comp = hn[0];
+    ss.g = g;
+    ss.thr = thr;
+    ss.nb = nb;
+    if (cf_out) *cf_out = (int32_t)hn[0];
+    return VCP_OK;
+  }
   hipLaunchKernelGGL(k_seedflag, dim3(nb), dim3(TPB), 0, st, parent, flags, minord, seedflag, cellcnt, g.ncells);
   hipLaunchKernelGGL(k_seed_popc, dim3(vcp_blocks(nw, TPB)), dim3(TPB), 0, st, seedflag, nw, seedpref);
   VCP_TRY(vcp_exclusive_scan_u32(ctx, seedpref, seedpref, nw, d_total));
@@ -1092,7 +1224,7 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   if (GROUPED) VCP_HIP(ctx, hipMemsetAsync(ext->d_group_twice, 0, (size_t)G * 4, st));
   hipLaunchKernelGGL(k_labk_rest, dim3(nb), dim3(TPB), 0, st, flags, parent, rootk, labk, cellcnt, g.ncells);
   hipLaunchKernelGGL((k_border<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup, flags,
-                     parent, sord, rootk, clseed, labk, counters, GROUPED ? ext->d_group_twice : nullptr, wlB);
+                     parent, sord, rootk, clseed, labk, counters, GROUPED ? ext->d_group_twice : nullptr, wlB, 0u, NONE);
   vcp_phase(ctx, "output");
   hipLaunchKernelGGL((k_output<GROUPED>), dim3(nb), dim3(TPB), 0, st, n, pos, labk, d_in_classed, d_group,
                      GROUPED ? ext->d_groupstart : nullptr, seedflag, seedpref, cf_in, d_labels, d_is_core, d_is_classed, counters);
@@ -1115,6 +1247,55 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   }
   if (cf_out) *cf_out = cf_in + (int32_t)K;
   if (dist_evals) *dist_evals = GROUPED ? (int64_t)hc[3] : (int64_t)(unclassed + hc[1] + K) * n;
+  return VCP_OK;
+}
+
+template <int GD, int METRIC>
+int run_slab_finish(vcp_ctx* ctx, const SlabState& ss, const uint32_t* d_map_rep, const uint32_t* d_map_k,
+                    const int32_t* d_tab_gid, uint32_t own_lo, uint32_t own_span, int32_t* d_labels,
+                    uint8_t* d_is_classed, int64_t* twice) {
+  hipStream_t st = ctx->stream;
+  const int64_t n = ss.n;
+  const unsigned nb = ss.nb;
+  const GridP g = ss.g;
+  uint32_t* cellcnt = ctx->b_cellcnt.as<uint32_t>();
+  uint32_t* pos = ctx->b_pos.as<uint32_t>();
+  double* sorted = ctx->b_sorted.as<double>();
+  uint32_t* sord = ctx->b_sidx.as<uint32_t>();
+  uint8_t* flags = ctx->b_flags.as<uint8_t>();
+  uint32_t* parent = ctx->b_parent.as<uint32_t>();
+  uint32_t* minord = ctx->b_minord.as<uint32_t>();
+  uint32_t* rootk = ctx->b_rootcl.as<uint32_t>();
+  uint32_t* clseed = ctx->b_clseed.as<uint32_t>();  // the caller's table of global seeds (copied in by now)
+  uint32_t* labk = ctx->b_labk.as<uint32_t>();
+  WorkList wlB;
+  uint32_t* blkE = ctx->b_wl.as<uint32_t>();
+  uint32_t* blkB = blkE + (nb + 2);
+  wlB.list = blkB + (nb + 2) + n;
+  wlB.scan = blkB;
+  wlB.nblk = nb;
+  wlB.perblk = (nb + 7) / 8;
+  const unsigned nbl = 8u * wlB.perblk;
+  const int rb = (int)vcp_blocks(n, TPB, 1024);
+  unsigned long long* counters = reinterpret_cast<unsigned long long*>(ctx->b_misc.as<double>() + (size_t)rb * 8 + 8);
+  vcp_phase(ctx, "slab_roots");
+  VCP_HIP(ctx, hipMemsetAsync(counters, 0, 4 * sizeof(unsigned long long), st));
+  hipLaunchKernelGGL(k_slab_rootk, dim3(nb), dim3(TPB), 0, st, parent, flags, minord, cellcnt, g.ncells, d_map_rep, d_map_k,
+                     (uint32_t)ss.n_comp, rootk, counters);
+  vcp_phase(ctx, "border");
+  hipLaunchKernelGGL(k_labk_rest, dim3(nb), dim3(TPB), 0, st, flags, parent, rootk, labk, cellcnt, g.ncells);
+  hipLaunchKernelGGL((k_border<GD, METRIC, false>), dim3(nbl), dim3(TPB), 0, st, sorted, g, ss.thr, cellcnt, nullptr, flags,
+                     parent, sord, rootk, clseed, labk, counters, nullptr, wlB, own_lo, own_span);
+  vcp_phase(ctx, "output");
+  hipLaunchKernelGGL(k_slab_output, dim3(nb), dim3(TPB), 0, st, n, pos, labk, d_tab_gid, d_labels, d_is_classed);
+  VCP_HIP(ctx, hipGetLastError());
+  unsigned long long* hc = reinterpret_cast<unsigned long long*>(ctx->pinned) + 8;
+  VCP_HIP(ctx, hipMemcpyAsync(hc, counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  VCP_TRY(vcp_phase_finish(ctx));
+  VCP_HIP(ctx, hipStreamSynchronize(st));
+  if (hc[0] != 0)
+    return vcp_fail(ctx, VCP_ERR_ARG, "%llu local components are missing from the map", hc[0]);
+  if (twice) *twice = (int64_t)hc[1];
   return VCP_OK;
 }
 
@@ -1164,6 +1345,7 @@ int vcp_dbscan_engine(vcp_ctx* ctx, const double* d_coords, int64_t n, int strid
     return vcp_fail(ctx, VCP_ERR_ARG, "grouped DBSCAN needs ord, groupstart, group_twice and the L1 metric");
   VCP_TRY(vcp_bind(ctx));
   vcp_phase_reset(ctx);
+  if (ctx->slab) ctx->slab->valid = false;  // the workspace is about to be overwritten
   if (n == 0) {
     if (cf_out) *cf_out = cf_in;
     if (dist_evals) *dist_evals = 0;
@@ -1185,6 +1367,88 @@ int vcp_dbscan_engine(vcp_ctx* ctx, const double* d_coords, int64_t n, int strid
 }
 
 extern "C" {
+
+void vcp_slab_state_free(vcp_ctx* ctx) {
+  delete ctx->slab;
+  ctx->slab = nullptr;
+}
+
+int vcp_slab_begin(vcp_ctx* ctx, const double* d_coords, int64_t n, int dim, int metric, double eps, int min_pts,
+                   const uint8_t* d_noexpand, const uint32_t* d_ord, uint32_t* d_rep, uint8_t* d_is_core,
+                   int64_t* n_comp) {
+  if (!ctx) return VCP_ERR_ARG;
+  if (n <= 0) return vcp_fail(ctx, VCP_ERR_ARG, "vcp_slab_begin needs n > 0");
+  if (!d_ord || !d_rep || !n_comp) return vcp_fail(ctx, VCP_ERR_ARG, "null buffer");
+  if (!(eps >= 0.0) || std::isinf(eps)) return vcp_fail(ctx, VCP_ERR_ARG, "staged DBSCAN needs a finite eps >= 0");
+  DbscanExt ext;
+  ext.d_ord = d_ord;
+  ext.slab = true;
+  ext.d_slab_rep = d_rep;
+  int32_t nc = 0;
+  // the labels argument is not written by a staged call; d_rep stands in for the null check
+  int rc = vcp_dbscan_engine(ctx, d_coords, n, dim, metric, eps, min_pts, 0, d_noexpand,
+                             reinterpret_cast<int32_t*>(d_rep), d_is_core, nullptr, &nc, nullptr, &ext);
+  if (rc != VCP_OK) return rc;
+  if (!ctx->slab || !ctx->slab->valid) return vcp_fail(ctx, VCP_ERR_ARG, "staged call did not reach the grid path");
+  *n_comp = ctx->slab->n_comp;
+  return VCP_OK;
+}
+
+int vcp_slab_comps(vcp_ctx* ctx, uint32_t* comp_rep) {
+  if (!ctx) return VCP_ERR_ARG;
+  if (!ctx->slab || !ctx->slab->valid) return vcp_fail(ctx, VCP_ERR_ARG, "no vcp_slab_begin state in this context");
+  if (ctx->slab->n_comp == 0) return VCP_OK;
+  if (!comp_rep) return vcp_fail(ctx, VCP_ERR_ARG, "null buffer");
+  VCP_TRY(vcp_bind(ctx));
+  VCP_HIP(ctx, hipMemcpyAsync(comp_rep, ctx->b_clseed.p, (size_t)ctx->slab->n_comp * 4, hipMemcpyDeviceToHost,
+                              ctx->stream));
+  VCP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VCP_OK;
+}
+
+int vcp_slab_finish(vcp_ctx* ctx, const uint32_t* map_rep, const uint32_t* map_k, int64_t n_tab,
+                    const int32_t* tab_gid, const uint32_t* tab_seed, uint32_t own_lo, uint32_t own_count,
+                    int32_t* d_labels, uint8_t* d_is_classed, int64_t* twice) {
+  if (!ctx) return VCP_ERR_ARG;
+  if (!ctx->slab || !ctx->slab->valid) return vcp_fail(ctx, VCP_ERR_ARG, "no vcp_slab_begin state in this context");
+  SlabState& ss = *ctx->slab;
+  if (!d_labels) return vcp_fail(ctx, VCP_ERR_ARG, "null buffer");
+  if (n_tab < 0 || n_tab > ss.n_comp) return vcp_fail(ctx, VCP_ERR_ARG, "cluster table larger than the component list");
+  if (ss.n_comp > 0 && (!map_rep || !map_k || !tab_gid || !tab_seed)) return vcp_fail(ctx, VCP_ERR_ARG, "null map");
+  for (int64_t k = 0; k < ss.n_comp; k++) {
+    if (k > 0 && map_rep[k] <= map_rep[k - 1]) return vcp_fail(ctx, VCP_ERR_ARG, "map_rep must be strictly ascending");
+    if ((int64_t)map_k[k] >= n_tab) return vcp_fail(ctx, VCP_ERR_ARG, "map_k out of range");
+  }
+  for (int64_t k = 1; k < n_tab; k++)
+    if (tab_gid[k] <= tab_gid[k - 1]) return vcp_fail(ctx, VCP_ERR_ARG, "tab_gid must be strictly ascending");
+  VCP_TRY(vcp_bind(ctx));
+  vcp_phase_reset(ctx);
+  hipStream_t st = ctx->stream;
+  const size_t L = (size_t)(ss.n_comp > 0 ? ss.n_comp : 1);
+  VCP_TRY(vcp_ensure(ctx, ctx->b_aux0, L * 4));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_aux1, L * 4));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_aux2, L * 4));
+  if (ss.n_comp > 0) {
+    VCP_HIP(ctx, hipMemcpyAsync(ctx->b_aux0.p, map_rep, (size_t)ss.n_comp * 4, hipMemcpyHostToDevice, st));
+    VCP_HIP(ctx, hipMemcpyAsync(ctx->b_aux1.p, map_k, (size_t)ss.n_comp * 4, hipMemcpyHostToDevice, st));
+  }
+  if (n_tab > 0) {
+    VCP_HIP(ctx, hipMemcpyAsync(ctx->b_aux2.p, tab_gid, (size_t)n_tab * 4, hipMemcpyHostToDevice, st));
+    VCP_HIP(ctx, hipMemcpyAsync(ctx->b_clseed.p, tab_seed, (size_t)n_tab * 4, hipMemcpyHostToDevice, st));
+  }
+  const uint32_t* mr = ctx->b_aux0.as<uint32_t>();
+  const uint32_t* mk = ctx->b_aux1.as<uint32_t>();
+  const int32_t* tg = ctx->b_aux2.as<int32_t>();
+  int rc;
+  if (ss.metric == VCP_L1_2D)
+    rc = run_slab_finish<2, VCP_L1_2D>(ctx, ss, mr, mk, tg, own_lo, own_count, d_labels, d_is_classed, twice);
+  else if (ss.metric == VCP_L2_2D)
+    rc = run_slab_finish<2, VCP_L2_2D>(ctx, ss, mr, mk, tg, own_lo, own_count, d_labels, d_is_classed, twice);
+  else
+    rc = run_slab_finish<3, VCP_L2_3D>(ctx, ss, mr, mk, tg, own_lo, own_count, d_labels, d_is_classed, twice);
+  ss.valid = false;
+  return rc;
+}
 
 int vcp_dbscan_dev(vcp_ctx* ctx, const double* d_coords, int64_t n, int dim, int metric, double eps,
                    int min_pts, int32_t cf_in, const uint8_t* d_in_classed, int32_t* d_labels,

@@ -15,6 +15,10 @@ struct DbscanExt {
   uint32_t* d_group_twice = nullptr;       // [G] zeroed by the engine; border points queried twice
   uint32_t* d_group_nclus = nullptr;       // [G] clusters found per group
   uint64_t* d_group_evals = nullptr;       // [1] sum over clustered groups of n_g*(n_g + K_g + twice_g)
+  // staged (slab) call: stop after the component build, leave the grid state in the context and write
+  // per point (caller order) the smallest ord of its component (0xFFFFFFFF if it is not expanding)
+  bool slab = false;
+  uint32_t* d_slab_rep = nullptr;
 };
 
 // d_* are device pointers; cf_out / dist_evals host pointers (may be null).  stride = doubles per point.

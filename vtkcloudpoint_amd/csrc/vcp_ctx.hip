@@ -238,12 +238,14 @@ int vcp_create(int device_id, vcp_ctx** out) {
 }
 
 void vcp_blocks_state_free(vcp_ctx* ctx);  // blocks.hip
+void vcp_slab_state_free(vcp_ctx* ctx);    // dbscan.hip
 
 void vcp_destroy(vcp_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   vcp_blocks_state_free(ctx);
+  vcp_slab_state_free(ctx);
   for (DevBuf* b : ctx->bufs)
     if (b->p) (void)hipFree(b->p);
   for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);

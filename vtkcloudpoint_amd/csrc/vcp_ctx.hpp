@@ -38,6 +38,7 @@ struct vcp_ctx {
       b_rootcl, b_clseed, b_scan_tmp, b_misc, b_in0, b_in1, b_in2, b_in3, b_out0, b_out1, b_out2,
       b_out3, b_icp_part, b_aux0, b_aux1, b_aux2, b_aux3, b_aux4, b_aux5, b_pos, b_labk, b_sgroup, b_wl;
   struct BlocksState* blocks = nullptr;  // staged block-partitioned pipeline (blocks.hip)
+  struct SlabState* slab = nullptr;      // staged exact multi-GPU DBSCAN (dbscan.hip: vcp_slab_*)
   // timing
   bool timing = false;
   std::vector<Phase> phases;

@@ -12,7 +12,16 @@ DBImproved per block, :1442-1520 sequential merge):
 * slab_cluster     every rank owns its own slab of a larger cloud (weak scaling): slabs are clustered
                    independently, cluster ids are made global with an exclusive scan of the per-rank
                    cluster counts, labels are all-gathered.
+
+And the exact form (SURVEY.md 8e mode 2):
+
+* exact_slabs      every rank owns a part of ONE cloud (the global list is the rank-major concatenation);
+                   the result is what a single DBImproved.dbscan over the whole list returns -- labels,
+                   core flags, cluster count and iritatorNum -- bit for bit.  Exchange: x-intervals, a
+                   2*eps halo of coordinates, the (point, local component) pairs of boundary points, and
+                   the ids of the clusters that cross a boundary.  All of it is O(boundary), not O(n).
 """
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -150,3 +159,212 @@ class SlabPipeline:
             if self.pending[b] is not None:
                 self.pending[b].wait()
                 self.pending[b] = None
+
+
+# ---------------------------------------------------------------------------------------------------
+# exact_slabs: one DBImproved.dbscan (BaseClass/DBImproved.cs:91-114) over a cloud spread over the ranks
+# ---------------------------------------------------------------------------------------------------
+def gather_rows(t, group=None):
+    """All-gather of a tensor whose first dimension differs per rank; returns the list of every rank's
+    tensor (padded to the largest for the collective: RCCL/gloo all-gathers want equal sizes)."""
+    rank, world = _world(group)
+    if world == 1:
+        return [t]
+    dev = t.device
+    cnt = torch.tensor([t.shape[0]], dtype=torch.int64, device=dev)
+    allc = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allc, cnt, group=group)
+    allc = allc.cpu().tolist()
+    width = max(allc)
+    tail = tuple(t.shape[1:])
+    if width == 0:
+        return [t.new_zeros((0,) + tail) for _ in range(world)]
+    send = t.new_zeros((width,) + tail)
+    send[: t.shape[0]] = t
+    recv = t.new_empty((world * width,) + tail)
+    dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+    return [recv[r * width: r * width + allc[r]] for r in range(world)]
+
+
+def _union_min(keys, reps):
+    """Classes of `reps` values linked by sharing a key.  Returns (unique reps ascending, smallest rep of the
+    class of each).  Host-side union-find over the boundary pairs only."""
+    u, inv = np.unique(reps, return_inverse=True)
+    parent = list(range(len(u)))
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+
+    order = np.argsort(keys, kind="stable")
+    ks, nodes = keys[order], inv[order]
+    same = np.nonzero(ks[1:] == ks[:-1])[0]
+    for t in same.tolist():
+        a, b = find(int(nodes[t])), find(int(nodes[t + 1]))
+        if a != b:  # nodes are ranks in the ascending unique list: the smaller index is the smaller rep
+            if a < b:
+                parent[b] = a
+            else:
+                parent[a] = b
+    fin = np.array([u[find(a)] for a in range(len(u))], dtype=u.dtype) if len(u) else u
+    return u, fin
+
+
+def _exact_slabs_steps(backend, coords, eps, min_pts, metric, cf_in, rank, world):
+    """The per-rank program of exact_slabs as a generator: it yields the tensor it contributes to each
+    exchange step and is sent back the list of all ranks' tensors (see exact_slabs / exact_slabs_local)."""
+    if not (eps >= 0.0) or eps == float("inf"):
+        raise ValueError("exact_slabs needs a finite eps >= 0")
+    n, dim = int(coords.shape[0]), int(coords.shape[1])
+    dev = coords.device
+    f64, i64 = torch.float64, torch.int64
+    x = coords[:, 0]
+    if n and not bool(torch.isfinite(coords).all()):
+        raise ValueError("exact_slabs needs finite coordinates")
+
+    # 1. x-interval and size of every rank's part; global position of my first point
+    if n:
+        info = torch.stack([x.min(), x.max(), torch.tensor(float(n), dtype=f64, device=dev)])
+    else:
+        info = torch.tensor([float("inf"), float("-inf"), 0.0], dtype=f64, device=dev)
+    allinfo = torch.stack((yield info.reshape(1, 3))).reshape(world, 3).cpu().numpy()
+    sizes = allinfo[:, 2].astype(np.int64)
+    gofs = int(sizes[:rank].sum())
+    n_total = int(sizes.sum())
+    if n_total >= 2 ** 31:
+        raise ValueError("exact_slabs: more than 2^31 points in total")
+    # margins: |dx| <= eps for every neighbour pair (each |dx| term is rounded once, the sum is monotone), so
+    # eps plus a relative 2^-20 and a few ulps of the largest coordinate covers every neighbour
+    amax = float(np.abs(allinfo[:, :2][np.isfinite(allinfo[:, :2])]).max()) if n_total else 0.0
+    m1 = eps * (1.0 + 2.0 ** -20) + 8.0 * np.spacing(amax) + 1e-300
+    m2 = 2.0 * m1
+    lo_me, hi_me = float(allinfo[rank, 0]), float(allinfo[rank, 1])
+
+    # 2. my points that lie within 2*eps of another rank's interval (coords + global position, one f64 tensor)
+    mask = torch.zeros(n, dtype=torch.bool, device=dev)
+    for s in range(world):
+        if s != rank and sizes[s] > 0:
+            mask |= (x >= float(allinfo[s, 0]) - m2) & (x <= float(allinfo[s, 1]) + m2)
+    sidx = torch.nonzero(mask).reshape(-1)
+    strip = torch.cat([coords[sidx], (sidx + gofs).to(f64).reshape(-1, 1)], dim=1)
+    strips = yield strip
+
+    # 3. halo = the other ranks' strip points within 2*eps of my interval; those within eps ("inner") have
+    #    their whole neighbourhood here, so their core flag is exact and they may extend clusters
+    parts = [strips[s] for s in range(world) if s != rank and strips[s].shape[0]]
+    if parts and n:
+        h = torch.cat(parts, dim=0)
+        hx = h[:, 0]
+        h = h[(hx >= lo_me - m2) & (hx <= hi_me + m2)]
+    else:
+        h = coords.new_zeros((0, dim + 1))
+    nh = int(h.shape[0])
+    hx = h[:, 0]
+    inner = (hx >= lo_me - m1) & (hx <= hi_me + m1)
+    out = dict(n=n, halo=nh, gofs=gofs)
+    labels = torch.zeros(max(n + nh, 1), dtype=torch.int32, device=dev)
+    is_core = torch.zeros(max(n + nh, 1), dtype=torch.uint8, device=dev)
+    is_classed = torch.zeros(max(n + nh, 1), dtype=torch.uint8, device=dev)
+    if n:
+        nl = n + nh
+        local = torch.cat([coords, h[:, :dim]], dim=0).contiguous() if nh else coords.contiguous()
+        ordv = torch.cat([torch.arange(gofs, gofs + n, dtype=i64, device=dev), h[:, dim].to(i64)]).to(torch.int32)
+        noexp = torch.cat([torch.zeros(n, dtype=torch.uint8, device=dev), (~inner).to(torch.uint8)])
+        rep = torch.empty(nl, dtype=torch.int32, device=dev)
+
+        # 4. grid, core flags, local components (HIP: vcp_slab_begin)
+        backend.slab_begin(local.data_ptr(), nl, dim, metric, float(eps), int(min_pts), noexp.data_ptr(),
+                           ordv.data_ptr(), rep.data_ptr(), is_core.data_ptr())
+        comps = np.asarray(backend.slab_comps(), dtype=np.uint32).astype(np.int64)  # ascending seeds
+        # 5. (point, local seed) for every expanding point another rank also sees, or that I see of theirs
+        cand = torch.cat([sidx, n + torch.nonzero(inner).reshape(-1)])
+        r = rep[cand]
+        keep = r != -1
+        pairs = torch.stack([ordv[cand][keep].to(i64), r[keep].to(i64)], dim=1)
+    else:
+        comps = np.zeros(0, np.int64)
+        pairs = torch.zeros((0, 2), dtype=i64, device=dev)
+    allpairs = torch.cat((yield pairs), dim=0).cpu().numpy()
+
+    # 6. components that cross a boundary: local seeds that share a point are one cluster; its seed is the
+    #    smallest of them (every member is owned by somebody, whose local seed is <= the member)
+    u, fin = _union_min(allpairs[:, 0], allpairs[:, 1])
+    if len(u):
+        at = np.minimum(np.searchsorted(u, comps), len(u) - 1)
+        inb = u[at] == comps
+        final = np.where(inb, fin[at], comps)
+    else:
+        inb = np.zeros(len(comps), bool)
+        final = comps.copy()
+
+    # 7. canonical numbering: cluster ids follow the global seeds in increasing order.  Each rank counts the
+    #    seeds it owns; ids of boundary clusters are published by the owner of the seed.
+    mine = (final == comps) & (comps >= gofs) & (comps < gofs + n)
+    myseeds = comps[mine]
+    counts = torch.cat((yield torch.tensor([[len(myseeds)]], dtype=i64, device=dev)), dim=0).cpu().numpy().reshape(-1)
+    base = int(cf_in) + int(counts[:rank].sum())
+    k_total = int(counts.sum())
+    myids = base + 1 + np.arange(len(myseeds), dtype=np.int64)
+    pubsel = inb[mine]
+    pub = torch.from_numpy(np.stack([myseeds[pubsel], myids[pubsel]], axis=1).reshape(-1, 2)).to(dev)
+    allpub = torch.cat((yield pub), dim=0).cpu().numpy()
+
+    if n:
+        # 8. global cluster of every local component, then the border rule and labels (HIP: vcp_slab_finish)
+        seeds_known = np.concatenate([myseeds, allpub[:, 0]])
+        ids_known = np.concatenate([myids, allpub[:, 1]])
+        o = np.argsort(seeds_known, kind="stable")
+        seeds_known, ids_known = seeds_known[o], ids_known[o]
+        at = np.minimum(np.searchsorted(seeds_known, final), max(len(seeds_known) - 1, 0))
+        if len(final) and (len(seeds_known) == 0 or not np.array_equal(seeds_known[at], final)):
+            raise RuntimeError("exact_slabs: a local component has no published global cluster")
+        gid = ids_known[at] if len(final) else np.zeros(0, np.int64)
+        tab_gid, map_k = np.unique(gid, return_inverse=True)
+        tab_seed = np.zeros(len(tab_gid), np.int64)
+        tab_seed[map_k] = final
+        twice = backend.slab_finish(comps.astype(np.uint32), map_k.astype(np.uint32), tab_gid.astype(np.int32),
+                                    tab_seed.astype(np.uint32), gofs, n, labels.data_ptr(), is_classed.data_ptr())
+    else:
+        twice = 0
+    # 9. iritatorNum of the monolithic call: n_total * (queried points + seeds + border points queried twice)
+    alltw = torch.cat((yield torch.tensor([[twice]], dtype=i64, device=dev)), dim=0).cpu().numpy().reshape(-1)
+    out.update(labels=labels[:n], is_core=is_core[:n], is_classed=is_classed[:n], cf=int(cf_in) + k_total,
+               dist_evals=n_total * (n_total + k_total + int(alltw.sum())), n_total=n_total,
+               boundary_pairs=int(allpairs.shape[0]))
+    return out
+
+
+def exact_slabs(backend, coords, eps, min_pts, metric=0, cf_in=0, group=None):
+    """DBImproved.dbscan over the rank-major concatenation of every rank's `coords` ([n_r, dim] float64 tensor
+    on this rank's device); each rank gets the labels / core flags of its own points.  `backend` provides
+    slab_begin / slab_comps / slab_finish (a vtkcloudpoint_amd._native.Context; the CPU tests pass the oracle's
+    stand-in).  Points may be distributed arbitrarily; the exchange stays small when ranks own x-slabs."""
+    rank, world = _world(group)
+    gen = _exact_slabs_steps(backend, coords, eps, min_pts, metric, cf_in, rank, world)
+    try:
+        msg = next(gen)
+        while True:
+            msg = gen.send(gather_rows(msg, group))
+    except StopIteration as e:
+        return e.value
+
+
+def exact_slabs_local(backends, parts, eps, min_pts, metric=0, cf_in=0):
+    """exact_slabs with every rank simulated in this process (one backend / context per part): the same
+    per-rank program, the exchange replaced by handing each rank the list of all contributions."""
+    world = len(parts)
+    gens = [_exact_slabs_steps(backends[r], parts[r], eps, min_pts, metric, cf_in, r, world) for r in range(world)]
+    msgs = [next(g) for g in gens]
+    results = [None] * world
+    while any(r is None for r in results):
+        nxt = []
+        for r, g in enumerate(gens):
+            try:
+                nxt.append(g.send(list(msgs)))
+            except StopIteration as e:
+                results[r] = e.value
+                nxt.append(None)
+        msgs = nxt
+    return results

@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=10_000_000)
     ap.add_argument("--metric", default="L1_2D", choices=["L1_2D", "L2_3D"])
+    ap.add_argument("--mode", default="slabs", choices=["slabs", "exact"],
+                    help="N>1: 'slabs' = every rank clusters its own cloud independently (ids made global, labels "
+                         "all-gathered); 'exact' = the ranks' clouds are adjacent x-slabs of ONE cloud and the result is "
+                         "the monolithic DBImproved.dbscan over all of it (halo exchange + boundary union)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the ICP / L2_3D side measurements")
     return ap.parse_args()
@@ -102,6 +106,12 @@ def main():
     eps = cloud["eps_l1"] if metric_id == N.L1_2D else cloud["eps_l2"]
     min_pts = cloud["min_pts"]
     dim = coords.shape[1]
+    exact = args.mode == "exact"
+    if exact:
+        # adjacent slabs of one cloud: rank r's points are shifted by r extents along x (exactly representable)
+        width = cloud["motor_extent"] if metric_id == N.L1_2D else 100.0 * (n / 1_000_000.0) ** (1.0 / 3.0)
+        coords = coords.copy()
+        coords[:, 0] += rank * float(np.ceil(width))
 
     dev = torch.device("cuda", local_rank)
     ctx = N.Context(local_rank)
@@ -116,13 +126,39 @@ def main():
 
     from vtkcloudpoint_amd import distributed as D
     pipe = None
-    if world > 1:
+    if exact:
+        class Timed:  # the staged engine resets its phase timers per call: collect after each stage
+            def __init__(self, c):
+                self.c, self.log = c, []
+
+            def slab_begin(self, *a):
+                r = self.c.slab_begin(*a)
+                self.log += self.c.timing()
+                return r
+
+            def slab_comps(self):
+                return self.c.slab_comps()
+
+            def slab_finish(self, *a):
+                r = self.c.slab_finish(*a)
+                self.log += self.c.timing()
+                return r
+        timed = Timed(ctx)
+    elif world > 1:
         # slabs clustered independently, ids made global on the device, int32 labels all-gathered over RCCL on a
         # second communicator so that the gather of step k overlaps the clustering of step k+1 (double buffered)
         big = dist.new_group(backend="nccl")
         pipe = D.SlabPipeline(ctx, n, dev, depth=2, group=None, big_group=big)
 
     def step(record):
+        if exact:
+            timed.log = []
+            r = D.exact_slabs(timed, d_coords, eps, min_pts, metric_id)
+            if record:
+                for name, ms in timed.log:
+                    phase_ms.setdefault(name, []).append(ms)
+                phase_ms.setdefault("halo_points", []).append(r["halo"])
+            return r["cf"], r["dist_evals"]
         if world > 1:
             allc, ev, _ = pipe.step(d_coords, dim, eps, min_pts, metric_id)
             cf = allc
@@ -162,6 +198,7 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = world * n / (dt / args.steps) / 1e6
         avg = {k: float(np.mean(v)) for k, v in phase_ms.items()}
+        halo = avg.pop("halo_points", None)
         dom = max(avg, key=avg.get)
         bpp = ALGO_BYTES_PER_POINT.get(dom, 0) if dim == 2 else ALGO_BYTES_PER_POINT.get(dom, 0) + 8
         achieved = bpp * n / (avg[dom] * 1e-3) / 1e9
@@ -183,8 +220,12 @@ def main():
                 "workload": "C4: %d-pt cloud per GPU (half uniform background, %d Gaussian blobs), "
                             "monolithic DBImproved.dbscan semantics, metric %s, eps %g, minPts %d%s"
                             % (n, n // 50_000, args.metric, eps, min_pts,
+                               "; ranks own adjacent x-slabs of one cloud, exact global result (2*eps halo + boundary "
+                               "union over RCCL, labels stay on the owning rank)" if exact else
                                "; slabs per rank + RCCL all-gather of int32 labels" if world > 1 else ""),
-                "points_per_gpu": n, "clusters": int(cf.sum().item()) if world > 1 else int(cf), "resident_in_hbm": True,
+                "points_per_gpu": n,
+                "clusters": int(cf) if (exact or world == 1) else int(cf.sum().item()), "resident_in_hbm": True,
+                "mode": args.mode if (world > 1 or exact) else "single",
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -195,6 +236,8 @@ def main():
             },
             "phase_ms": {k: round(v, 4) for k, v in avg.items()},
         }
+        if halo is not None:
+            out["config"]["halo_points_rank0"] = halo
 
     # ---- side measurements on rank 0 at N=1: ICP (C3) ---------------------------------------------
     if rank == 0 and world == 1 and not args.no_extras:

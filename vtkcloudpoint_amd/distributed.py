@@ -148,6 +148,8 @@ class SlabPipeline:
         if self.pending[b] is not None:
             self.pending[b].wait()  # the buffer pair is free again
             self.pending[b] = None
+            if self.labels[b].is_cuda:  # wait() only orders torch's stream; the library writes on its own
+                torch.cuda.current_stream(self.labels[b].device).synchronize()
         lab = self.labels[b]
         allc, ev = slab_cluster(self.ctx, d_coords, self.n, dim, eps, min_pts, metric, lab, None, self.group)
         if self.world > 1:
@@ -164,19 +166,24 @@ class SlabPipeline:
 # ---------------------------------------------------------------------------------------------------
 # exact_slabs: one DBImproved.dbscan (BaseClass/DBImproved.cs:91-114) over a cloud spread over the ranks
 # ---------------------------------------------------------------------------------------------------
-def gather_rows(t, group=None):
+def gather_rows(t, group=None, fixed=False):
     """All-gather of a tensor whose first dimension differs per rank; returns the list of every rank's
-    tensor (padded to the largest for the collective: RCCL/gloo all-gathers want equal sizes)."""
+    tensor (padded to the largest for the collective: RCCL/gloo all-gathers want equal sizes).  fixed=True:
+    every rank sends the same shape, no size exchange."""
     rank, world = _world(group)
     if world == 1:
         return [t]
     dev = t.device
+    tail = tuple(t.shape[1:])
+    if fixed:
+        recv = t.new_empty((world * t.shape[0],) + tail)
+        dist.all_gather_into_tensor(recv, t.contiguous(), group=group)
+        return list(recv.split(t.shape[0]))
     cnt = torch.tensor([t.shape[0]], dtype=torch.int64, device=dev)
     allc = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(allc, cnt, group=group)
     allc = allc.cpu().tolist()
     width = max(allc)
-    tail = tuple(t.shape[1:])
     if width == 0:
         return [t.new_zeros((0,) + tail) for _ in range(world)]
     send = t.new_zeros((width,) + tail)
@@ -229,7 +236,7 @@ def _exact_slabs_steps(backend, coords, eps, min_pts, metric, cf_in, rank, world
         info = torch.stack([x.min(), x.max(), torch.tensor(float(n), dtype=f64, device=dev)])
     else:
         info = torch.tensor([float("inf"), float("-inf"), 0.0], dtype=f64, device=dev)
-    allinfo = torch.stack((yield info.reshape(1, 3))).reshape(world, 3).cpu().numpy()
+    allinfo = torch.stack((yield info.reshape(1, 3), True)).reshape(world, 3).cpu().numpy()
     sizes = allinfo[:, 2].astype(np.int64)
     gofs = int(sizes[:rank].sum())
     n_total = int(sizes.sum())
@@ -249,7 +256,7 @@ def _exact_slabs_steps(backend, coords, eps, min_pts, metric, cf_in, rank, world
             mask |= (x >= float(allinfo[s, 0]) - m2) & (x <= float(allinfo[s, 1]) + m2)
     sidx = torch.nonzero(mask).reshape(-1)
     strip = torch.cat([coords[sidx], (sidx + gofs).to(f64).reshape(-1, 1)], dim=1)
-    strips = yield strip
+    strips = yield strip, False
 
     # 3. halo = the other ranks' strip points within 2*eps of my interval; those within eps ("inner") have
     #    their whole neighbourhood here, so their core flag is exact and they may extend clusters
@@ -274,7 +281,10 @@ def _exact_slabs_steps(backend, coords, eps, min_pts, metric, cf_in, rank, world
         noexp = torch.cat([torch.zeros(n, dtype=torch.uint8, device=dev), (~inner).to(torch.uint8)])
         rep = torch.empty(nl, dtype=torch.int32, device=dev)
 
-        # 4. grid, core flags, local components (HIP: vcp_slab_begin)
+        # 4. grid, core flags, local components (HIP: vcp_slab_begin).  The library runs on its own stream:
+        #    what torch queued above must have landed first.
+        if dev.type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()
         backend.slab_begin(local.data_ptr(), nl, dim, metric, float(eps), int(min_pts), noexp.data_ptr(),
                            ordv.data_ptr(), rep.data_ptr(), is_core.data_ptr())
         comps = np.asarray(backend.slab_comps(), dtype=np.uint32).astype(np.int64)  # ascending seeds
@@ -286,7 +296,7 @@ def _exact_slabs_steps(backend, coords, eps, min_pts, metric, cf_in, rank, world
     else:
         comps = np.zeros(0, np.int64)
         pairs = torch.zeros((0, 2), dtype=i64, device=dev)
-    allpairs = torch.cat((yield pairs), dim=0).cpu().numpy()
+    allpairs = torch.cat((yield pairs, False), dim=0).cpu().numpy()
 
     # 6. components that cross a boundary: local seeds that share a point are one cluster; its seed is the
     #    smallest of them (every member is owned by somebody, whose local seed is <= the member)
@@ -303,18 +313,23 @@ def _exact_slabs_steps(backend, coords, eps, min_pts, metric, cf_in, rank, world
     #    seeds it owns; ids of boundary clusters are published by the owner of the seed.
     mine = (final == comps) & (comps >= gofs) & (comps < gofs + n)
     myseeds = comps[mine]
-    counts = torch.cat((yield torch.tensor([[len(myseeds)]], dtype=i64, device=dev)), dim=0).cpu().numpy().reshape(-1)
-    base = int(cf_in) + int(counts[:rank].sum())
+    pubsel = np.nonzero(inb[mine])[0]
+    msg = np.empty((1 + len(pubsel), 2), np.int64)  # row 0: (my seed count, -1); then (seed, its rank among mine)
+    msg[0] = (len(myseeds), -1)
+    msg[1:, 0] = myseeds[pubsel]
+    msg[1:, 1] = pubsel
+    allmsg = [m.cpu().numpy() for m in (yield torch.from_numpy(msg).to(dev), False)]
+    counts = np.array([int(m[0, 0]) for m in allmsg], np.int64)
+    bases = int(cf_in) + np.concatenate([[0], np.cumsum(counts)[:-1]])
     k_total = int(counts.sum())
-    myids = base + 1 + np.arange(len(myseeds), dtype=np.int64)
-    pubsel = inb[mine]
-    pub = torch.from_numpy(np.stack([myseeds[pubsel], myids[pubsel]], axis=1).reshape(-1, 2)).to(dev)
-    allpub = torch.cat((yield pub), dim=0).cpu().numpy()
+    myids = int(bases[rank]) + 1 + np.arange(len(myseeds), dtype=np.int64)
+    pub_seed = np.concatenate([m[1:, 0] for m in allmsg])
+    pub_id = np.concatenate([bases[q] + 1 + m[1:, 1] for q, m in enumerate(allmsg)])
 
     if n:
         # 8. global cluster of every local component, then the border rule and labels (HIP: vcp_slab_finish)
-        seeds_known = np.concatenate([myseeds, allpub[:, 0]])
-        ids_known = np.concatenate([myids, allpub[:, 1]])
+        seeds_known = np.concatenate([myseeds, pub_seed])
+        ids_known = np.concatenate([myids, pub_id])
         o = np.argsort(seeds_known, kind="stable")
         seeds_known, ids_known = seeds_known[o], ids_known[o]
         at = np.minimum(np.searchsorted(seeds_known, final), max(len(seeds_known) - 1, 0))
@@ -329,7 +344,7 @@ def _exact_slabs_steps(backend, coords, eps, min_pts, metric, cf_in, rank, world
     else:
         twice = 0
     # 9. iritatorNum of the monolithic call: n_total * (queried points + seeds + border points queried twice)
-    alltw = torch.cat((yield torch.tensor([[twice]], dtype=i64, device=dev)), dim=0).cpu().numpy().reshape(-1)
+    alltw = torch.cat((yield torch.tensor([[twice]], dtype=i64, device=dev), True), dim=0).cpu().numpy().reshape(-1)
     out.update(labels=labels[:n], is_core=is_core[:n], is_classed=is_classed[:n], cf=int(cf_in) + k_total,
                dist_evals=n_total * (n_total + k_total + int(alltw.sum())), n_total=n_total,
                boundary_pairs=int(allpairs.shape[0]))
@@ -344,9 +359,9 @@ def exact_slabs(backend, coords, eps, min_pts, metric=0, cf_in=0, group=None):
     rank, world = _world(group)
     gen = _exact_slabs_steps(backend, coords, eps, min_pts, metric, cf_in, rank, world)
     try:
-        msg = next(gen)
+        msg, fixed = next(gen)
         while True:
-            msg = gen.send(gather_rows(msg, group))
+            msg, fixed = gen.send(gather_rows(msg, group, fixed))
     except StopIteration as e:
         return e.value
 
@@ -356,13 +371,13 @@ def exact_slabs_local(backends, parts, eps, min_pts, metric=0, cf_in=0):
     per-rank program, the exchange replaced by handing each rank the list of all contributions."""
     world = len(parts)
     gens = [_exact_slabs_steps(backends[r], parts[r], eps, min_pts, metric, cf_in, r, world) for r in range(world)]
-    msgs = [next(g) for g in gens]
+    msgs = [next(g)[0] for g in gens]
     results = [None] * world
     while any(r is None for r in results):
         nxt = []
         for r, g in enumerate(gens):
             try:
-                nxt.append(g.send(list(msgs)))
+                nxt.append(g.send(list(msgs))[0])
             except StopIteration as e:
                 results[r] = e.value
                 nxt.append(None)

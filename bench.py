@@ -194,6 +194,20 @@ def main():
         dt = float(t.item())
 
     out = None
+    copy_gbs = None
+    if rank == 0:
+        # measured device-copy ceiling: 1 GiB device-to-device copy, read + write bytes per second
+        a = torch.empty(1 << 27, dtype=torch.float64, device=dev)
+        b = torch.empty_like(a)
+        b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * a.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a, b
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * n / (dt / args.steps) / 1e6
@@ -230,6 +244,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "copy_ceiling_GBs": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs,
                 "algorithmic_bytes_per_point": bpp, "kernel_ms": avg[dom],
                 "pipeline_algorithmic_bytes_per_point": total_bpp,
                 "pipeline_achieved_GBs": total_bpp * n / (ms_per_step * 1e-3) / 1e9,

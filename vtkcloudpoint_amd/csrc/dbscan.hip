@@ -38,6 +38,10 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 #ifndef VCP_UNR3
 #define VCP_UNR3 2
 #endif
+// the same for loops whose first load per candidate is one 4-byte word (k_union after phases 1-2, k_border)
+#ifndef VCP_UNRW
+#define VCP_UNRW 4
+#endif
 
 struct GridP {
   double mn[3];
@@ -287,6 +291,24 @@ __device__ __forceinline__ void for_rows(const int* cc, const GridP& g, const ui
       if (!f(rs[r], re[r])) return;
 }
 
+// the same bounds as plain arrays, for kernels that keep per-lane state across rows (a loop body that is not
+// a lambda keeps that state in registers)
+template <int GD>
+__device__ __forceinline__ void row_bounds(const int* cc, const GridP& g, const uint32_t* __restrict__ cellstart,
+                                           uint32_t* rs, uint32_t* re) {
+  constexpr int NR = GD == 3 ? 9 : 3;
+  const int x0 = max(cc[0] - 1, 0), x1 = min(cc[0] + 1, g.D[0] - 1);
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    const int y = cc[1] + (r % 3) - 1;
+    const int z = GD == 3 ? cc[2] + (r / 3) - 1 : 0;
+    const bool ok = y >= 0 && y < g.D[1] && (GD != 3 || (z >= 0 && z < g.D[2]));
+    const uint32_t base = ok ? cell_id<GD>(g, 0, y, z) : 0u;
+    rs[r] = ok ? cellstart[base + x0] : 0u;
+    re[r] = ok ? cellstart[base + x1 + 1] : 0u;
+  }
+}
+
 // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  The neighbour-search kernels
 // remap the block index so that each XCD walks ONE contiguous eighth of the cell-ordered arrays: a point's
 // neighbour rows are then (mostly) in its own XCD's 4 MiB L2.  Speed only, never correctness.
@@ -309,10 +331,14 @@ struct WorkList {
   uint32_t nblk;
 };
 
-// position handled by this thread of a list kernel, or NONE
+// position handled by this thread of a list kernel, or NONE.  Block b works in eighth (b & 7) of the LIST
+// (equal entry counts per XCD; eighths of the position range were up to 34 % apart in entries on the C4
+// cloud, and the slowest XCD sets the kernel time).  The list is in position order, so an eighth is still one
+// contiguous band of the cell-ordered arrays.
 __device__ __forceinline__ uint32_t wl_fetch(const WorkList& w) {
+  const uint32_t total = w.scan[w.nblk];
   const uint32_t r = blockIdx.x & 7u;
-  const uint32_t lo = w.scan[min(r * w.perblk, w.nblk)], hi = w.scan[min((r + 1u) * w.perblk, w.nblk)];
+  const uint32_t lo = (uint32_t)(((uint64_t)total * r) >> 3), hi = (uint32_t)(((uint64_t)total * (r + 1u)) >> 3);
   const uint32_t t = lo + (blockIdx.x >> 3) * TPB + threadIdx.x;
   if (t >= hi) return NONE;
   return w.list[t];
@@ -426,6 +452,140 @@ __global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted,
   wl_count(isE, isB, (uint32_t)blk, blkE, blkB);
 }
 
+// ---- LDS-staged candidate rows (2-D, ungrouped) -----------------------------------------------------
+// A workgroup covers 256 consecutive positions = a run of cells along x, so the three candidate rows of all
+// its lanes are (almost always) three short contiguous position ranges.  They are staged once per workgroup
+// (coalesced 16-B loads) and every lane scans its own sub-range from LDS instead of re-fetching the same lines
+// through L1 per lane.  If a staged range would exceed the tile (dense cells, a block spanning grid rows far
+// apart) the workgroup uses the global-memory loop.
+constexpr int TILE_CAP = 512;  // staged points per row: 3 x 512 x 16 B = 24 KB of LDS per workgroup
+
+struct RowTile {
+  double2 pt[3][TILE_CAP];
+  uint32_t lo[3], hi[3];
+};
+
+// row bounds of this lane (rs >= re for a missing row) and the workgroup's union per row in t.lo / t.hi;
+// returns true when all three ranges fit the tile (uniform over the workgroup)
+template <class Tile, int CAP>
+__device__ __forceinline__ bool tile_bounds(Tile& t, bool live, const int* cc, const GridP& g,
+                                            const uint32_t* __restrict__ cellstart, uint32_t* rs, uint32_t* re) {
+  if (threadIdx.x < 3) {
+    t.lo[threadIdx.x] = NONE;
+    t.hi[threadIdx.x] = 0u;
+  }
+  const int x0 = max(cc[0] - 1, 0), x1 = min(cc[0] + 1, g.D[0] - 1);
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const int y = cc[1] + r - 1;
+    const bool ok = live && y >= 0 && y < g.D[1];
+    const uint32_t base = ok ? cell_id<2>(g, 0, y, 0) : 0u;
+    rs[r] = ok ? cellstart[base + x0] : 0u;
+    re[r] = ok ? cellstart[base + x1 + 1] : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    uint32_t a = rs[r] < re[r] ? rs[r] : NONE, b = rs[r] < re[r] ? re[r] : 0u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      a = min(a, (uint32_t)__shfl_xor((int)a, d, 64));
+      b = max(b, (uint32_t)__shfl_xor((int)b, d, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(&t.lo[r], a);
+      atomicMax(&t.hi[r], b);
+    }
+  }
+  __syncthreads();
+  bool fits = true;
+#pragma unroll
+  for (int r = 0; r < 3; r++) fits = fits && (t.hi[r] <= t.lo[r] || t.hi[r] - t.lo[r] <= (uint32_t)CAP);
+  return fits;
+}
+
+__device__ __forceinline__ void tile_load(RowTile& t, const double* __restrict__ sorted) {
+  const double2* __restrict__ src = reinterpret_cast<const double2*>(sorted);
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const uint32_t lo = t.lo[r], hi = t.hi[r];
+    if (hi > lo)
+      for (uint32_t k = threadIdx.x; k < hi - lo; k += TPB) t.pt[r][k] = src[lo + k];
+  }
+  __syncthreads();
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sorted, GridP g, double thr, int min_pts,
+                                                 const uint32_t* __restrict__ cellstart, uint8_t* __restrict__ flags,
+                                                 uint32_t* __restrict__ blkE, uint32_t* __restrict__ blkB) {
+  __shared__ RowTile t;
+  const uint32_t nin = cellstart[g.ncells];
+  const int64_t blk = xcd_block(gridDim.x);
+  int64_t p = blk * TPB + threadIdx.x;
+  const bool live = p < nin;
+  double q[3] = {0, 0, 0};
+  int cc[3] = {0, 0, 0};
+  if (live) {
+    load_pt<2>(sorted, p, q);
+    cell_of<2>(q, g, cc);
+  }
+  uint32_t rs[3], re[3];
+  const bool fits = tile_bounds<RowTile, TILE_CAP>(t, live, cc, g, cellstart, rs, re);
+  constexpr int UNR = VCP_UNR2;
+  int cnt = 0;
+  if (fits) {
+    tile_load(t, sorted);
+    if (live) {
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        if (cnt >= min_pts || rs[r] >= re[r]) continue;
+        const uint32_t lo = t.lo[r];
+        const uint32_t e = re[r] - lo;
+        for (uint32_t j = rs[r] - lo; j < e; j += UNR) {
+          double2 c[UNR];
+#pragma unroll
+          for (int u = 0; u < UNR; u++) c[u] = t.pt[r][min(j + u, e - 1)];
+#pragma unroll
+          for (int u = 0; u < UNR; u++) {
+            const double rr[3] = {c[u].x, c[u].y, 0.0};
+            cnt += ((j + u < e) && within<METRIC>(q, rr, thr)) ? 1 : 0;
+          }
+          if (cnt >= min_pts) break;
+        }
+      }
+    }
+  } else if (live) {
+    for (int r = 0; r < 3 && cnt < min_pts; r++) {
+      for (uint32_t j = rs[r]; j < re[r]; j += UNR) {
+        double rr[UNR][3];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) load_pt<2>(sorted, min(j + u, re[r] - 1), rr[u]);
+#pragma unroll
+        for (int u = 0; u < UNR; u++) cnt += ((j + u < re[r]) && within<METRIC>(q, rr[u], thr)) ? 1 : 0;
+        if (cnt >= min_pts) break;
+      }
+    }
+  }
+  uint8_t fl = live ? flags[p] : 0;
+  bool isE = false, isB = false;
+  if (!live) {
+  } else if (cnt >= min_pts) {
+    fl |= F_CORE;
+    if (!(fl & F_CLASSED)) {
+      fl |= F_EXPAND;
+      isE = true;
+    } else {
+      isB = true;
+    }
+  } else {
+    isB = cnt > 1;
+  }
+  if (isB) fl |= F_BCAND;
+  if (live) flags[p] = fl;
+  wl_count(isE, isB, (uint32_t)blk, blkE, blkB);
+}
+
 // ---- union-find over expanding points -------------------------------------------------------------
 // Pointers always go from a larger to a smaller position, so the forest stays acyclic under any
 // interleaving.  Loads may be stale (another XCD's L2): a stale value is an OLDER ancestor link, still
@@ -465,12 +625,15 @@ __device__ __forceinline__ uint32_t uf_link(uint32_t* parent, uint32_t ra, uint3
   return ra;
 }
 
+// parent[p] = p for expanding points, NONE for all others: the component kernels can then tell "expanding and
+// in which tree" from ONE 4-byte load per candidate
 __global__ __launch_bounds__(TPB) void k_init_parent(uint32_t* __restrict__ parent, uint32_t* __restrict__ minord,
+                                                    const uint8_t* __restrict__ flags,
                                                     const uint32_t* __restrict__ cellstart, uint32_t ncells) {
   const uint32_t nin = cellstart[ncells];
   int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
   if (p >= nin) return;
-  parent[p] = (uint32_t)p;
+  parent[p] = (flags[p] & F_EXPAND) ? (uint32_t)p : NONE;
   minord[p] = NONE;
 }
 
@@ -516,45 +679,6 @@ __global__ __launch_bounds__(TPB) void k_union_init(const double* __restrict__ s
   if (first != me) parent[me] = first;
 }
 
-// Phase 2b: every tree root looks at ALL its expanding neighbours (both directions) and, if one of them
-// sits in a tree with a smaller root, hangs itself under that root.  Only the root's own thread writes its
-// parent and pointers only decrease: still a forest, no atomics.  Repeated with a flatten in between this
-// merges neighbouring trees Boruvka-style, so that phase 3 finds almost every edge already inside one tree.
-template <int GD, int METRIC, bool GROUPED>
-__global__ __launch_bounds__(TPB) void k_root_hook(const double* __restrict__ sorted, GridP g, double thr,
-                                                  const uint32_t* __restrict__ cellstart,
-                                                  const int32_t* __restrict__ sgroup, const uint8_t* __restrict__ flags,
-                                                  uint32_t* __restrict__ parent, WorkList wlE) {
-  const uint32_t p = wl_fetch(wlE);
-  if (p == NONE) return;
-  if (ld_parent_cached(parent, p) != p) return;  // not a root
-  double q[3];
-  int cc[3];
-  load_pt<GD>(sorted, p, q);
-  cell_of<GD>(q, g, cc);
-  constexpr int UNR = GD == 3 ? VCP_UNR3 : VCP_UNR2;
-  const int32_t myg = GROUPED ? sgroup[p] : 0;
-  uint32_t best = p;
-  for_rows<GD>(cc, g, cellstart, [&](uint32_t s, uint32_t e) {
-    for (uint32_t j0 = s; j0 < e; j0 += UNR) {
-      double rr[UNR][3];
-      bool cand[UNR];
-#pragma unroll
-      for (int u = 0; u < UNR; u++) {
-        const uint32_t jj = min(j0 + u, e - 1);
-        cand[u] = (j0 + u < e) && (flags[jj] & F_EXPAND);
-        if (GROUPED) cand[u] = cand[u] && sgroup[jj] == myg;
-        load_pt<GD>(sorted, jj, rr[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < UNR; u++)
-        if (cand[u] && within<METRIC>(q, rr[u], thr)) best = min(best, ld_parent_cached(parent, j0 + u));
-    }
-    return true;
-  });
-  if (best < p) __hip_atomic_store(&parent[p], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-}
-
 // Phase 2: flatten the phase-1 forest (no atomics; a racing reader sees an older or a newer ancestor)
 __global__ __launch_bounds__(TPB) void k_flatten0(uint32_t* __restrict__ parent, const uint8_t* __restrict__ flags,
                                                  const uint32_t* __restrict__ cellstart, uint32_t ncells) {
@@ -570,75 +694,130 @@ __global__ __launch_bounds__(TPB) void k_flatten0(uint32_t* __restrict__ parent,
   __hip_atomic_store(&parent[p], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
-// Phase 3: all remaining core-core edges.  Most are already inside one phase-1/2 tree (one cached load tells);
-// the rest hook tree roots together with a device-scope CAS.
-template <int GD, int METRIC, bool GROUPED>
+// Phase 3: all remaining core-core edges.  PRE (2-D, after phases 1-2): the candidate's parent word is read
+// FIRST -- NONE = not expanding, my own cached root = already in my tree (the common case inside a cluster) --
+// and only candidates in a different tree pay for the coordinate load and the binary64 test.  Confirmed edges
+// into other trees are queued (by the other side's parent word, at most two) and joined after the scan, so that
+// the find/CAS latency chains of all lanes of a wave overlap instead of each lane stalling the other 63 at a
+// different trip of the scan loop.  Without phases 1-2 (3-D) every candidate is in a different tree at the
+// start, so the distance test goes first and edges are joined on the spot.
+#define VCP_JOIN(x)                                                \
+  do {                                                             \
+    const uint32_t rx__ = uf_root(parent, (x));                    \
+    const uint32_t rm__ = uf_root(parent, rp);                     \
+    rp = (rx__ != rm__) ? uf_link(parent, rm__, rx__) : rm__;      \
+  } while (0)
+#define VCP_FLUSH()                                                \
+  do {                                                             \
+    if (q0 != NONE) {                                              \
+      const uint32_t old__ = rp;                                   \
+      VCP_JOIN(q0);                                                \
+      a2 = a0;                                                     \
+      a0 = q0;                                                     \
+      a1 = old__;                                                  \
+    }                                                              \
+    if (q1 != NONE) {                                              \
+      VCP_JOIN(q1);                                                \
+      a2 = q1;                                                     \
+    }                                                              \
+    q0 = q1 = NONE;                                                \
+  } while (0)
+
+template <int GD, int METRIC, bool GROUPED, bool PRE>
 __global__ __launch_bounds__(TPB) void k_union(const double* __restrict__ sorted, GridP g, double thr,
                                               const uint32_t* __restrict__ cellstart,
-                                              const int32_t* __restrict__ sgroup, const uint8_t* __restrict__ flags,
-                                              uint32_t* __restrict__ parent, int dbg, WorkList wlE,
-                                              unsigned long long* __restrict__ dbgc) {
+                                              const int32_t* __restrict__ sgroup, uint32_t* __restrict__ parent,
+                                              WorkList wlE) {
   const uint32_t p = wl_fetch(wlE);
   if (p == NONE) return;
-  unsigned c_edge = 0, c_f1 = 0, c_f2 = 0, c_slow = 0, c_link = 0;
   double q[3];
   int cc[3];
   load_pt<GD>(sorted, p, q);
   cell_of<GD>(q, g, cc);
-  constexpr int UNR = GD == 3 ? VCP_UNR3 : VCP_UNR2;
+  constexpr int UNR = PRE ? VCP_UNRW : (GD == 3 ? VCP_UNR3 : VCP_UNR2);
+  constexpr int NR = GD == 3 ? 9 : 3;
   const int32_t myg = GROUPED ? sgroup[p] : 0;
   const uint32_t me = (uint32_t)p;
   uint32_t rp = parent[me];  // cached root of my tree (flattened by phase 2)
-  for_rows<GD>(cc, g, cellstart, [&](uint32_t s, uint32_t e) {
-    if (s >= me) return true;   // every undirected edge is handled by its larger endpoint
-    if (e > me) e = me;
+  // q0,q1 = queued edges; a0..a2 = words known to be in my tree
+  uint32_t q0 = NONE, q1 = NONE, a0 = NONE, a1 = NONE, a2 = NONE;
+  uint32_t rs[NR], re[NR];
+  row_bounds<GD>(cc, g, cellstart, rs, re);
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    const uint32_t s = rs[r];
+    const uint32_t e = min(re[r], me);  // every undirected edge is handled by its larger endpoint
     for (uint32_t j0 = s; j0 < e; j0 += UNR) {
-      double rr[UNR][3];
-      bool cand[UNR];
+      uint32_t pj[UNR];
+      double2 xy[UNR];
+      double zz[UNR];
 #pragma unroll
       for (int u = 0; u < UNR; u++) {
         const uint32_t jj = min(j0 + u, e - 1);
-        cand[u] = (j0 + u < e) && (flags[jj] & F_EXPAND);
-        if (GROUPED) cand[u] = cand[u] && sgroup[jj] == myg;
-        load_pt<GD>(sorted, jj, rr[u]);
+        pj[u] = ld_parent_cached(parent, jj);
+        if (!PRE) {
+          if (GD == 2) {
+            xy[u] = *reinterpret_cast<const double2*>(sorted + 2 * (int64_t)jj);
+          } else {
+            xy[u] = make_double2(sorted[3 * (int64_t)jj], sorted[3 * (int64_t)jj + 1]);
+            zz[u] = sorted[3 * (int64_t)jj + 2];
+          }
+        }
       }
 #pragma unroll
       for (int u = 0; u < UNR; u++) {
-      const uint32_t j = j0 + u;
-      if (!cand[u] || !within<METRIC>(q, rr[u], thr)) continue;
-      if (dbg == 1) { rp = min(rp, j); continue; }
-      uint32_t pj = ld_parent_cached(parent, j);
-      if (dbg == 2) { rp = min(rp, pj); continue; }
-      c_edge++;
-      if (pj == rp) { c_f1++; continue; }  // already under my root (the common case inside a cluster)
-      // second hop: j's tree was hooked under my root by an earlier edge (one L2 load instead of two chases)
-      uint32_t pj2 = ld_parent(parent, pj);
-      if (pj2 == rp) {
-        c_f2++;
-        __hip_atomic_store(&parent[j], rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        continue;
-      }
-      c_slow++;
-      uint32_t rj = uf_root(parent, pj2);
-      rp = uf_root(parent, rp);
-      if (rj != rp) { c_link++; rp = uf_link(parent, rp, rj); }
-      // compress j's pointer (rp is now an ancestor of j); cached store, same-XCD readers profit
-      if (dbg != 3 && pj != rp && j != rp)
-        __hip_atomic_store(&parent[j], rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const uint32_t j = j0 + u, x = pj[u];
+        // NONE = not expanding; my root or a word known to be in my tree = nothing to do; a word already
+        // queued = that tree is being joined anyway
+        if (j >= e || x == NONE || x == rp) continue;
+        if (PRE && (x == a0 || x == a1 || x == a2 || x == q0 || x == q1)) continue;
+        if (GROUPED && sgroup[j] != myg) continue;
+        if (PRE) {
+          if (GD == 2) {
+            xy[u] = *reinterpret_cast<const double2*>(sorted + 2 * (int64_t)j);
+          } else {
+            xy[u] = make_double2(sorted[3 * (int64_t)j], sorted[3 * (int64_t)j + 1]);
+            zz[u] = sorted[3 * (int64_t)j + 2];
+          }
+        }
+        const double dx = q[0] - xy[u].x, dy = q[1] - xy[u].y;
+        bool hit;
+        if (METRIC == VCP_L1_2D) {
+          hit = fabs(dx) + fabs(dy) <= thr;
+        } else if (METRIC == VCP_L2_2D) {
+          hit = dx * dx + dy * dy <= thr;
+        } else {
+          const double dz = q[2] - zz[u];
+          hit = dx * dx + dy * dy + dz * dz <= thr;
+        }
+        if (!hit) continue;
+        if (!PRE) {
+          // second hop: j's tree was hooked under my root by an earlier edge (one L2 load instead of two chases)
+          const uint32_t x2 = ld_parent(parent, x);
+          if (x2 != rp) {
+            const uint32_t rx = uf_root(parent, x2);
+            const uint32_t rm = uf_root(parent, rp);
+            rp = (rx != rm) ? uf_link(parent, rm, rx) : rm;
+          }
+          // compress j's pointer (rp is an ancestor of j now); cached store, same-XCD readers profit
+          if (x != rp && j != rp) __hip_atomic_store(&parent[j], rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        } else if (q0 == NONE) {
+          q0 = x;
+        } else if (q1 == NONE) {
+          q1 = x;
+        } else {
+          VCP_FLUSH();
+          q0 = x;
+        }
       }
     }
-    return true;
-  });
+  }
+  VCP_FLUSH();
   // one compression store per point (rp is an ancestor of me, so the link stays valid)
   if (rp != me) __hip_atomic_store(&parent[me], rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (dbg == 5) {
-    atomicAdd(&dbgc[0], (unsigned long long)c_edge);
-    atomicAdd(&dbgc[1], (unsigned long long)c_f1);
-    atomicAdd(&dbgc[2], (unsigned long long)c_f2);
-    atomicAdd(&dbgc[3], (unsigned long long)c_slow);
-    atomicAdd(&dbgc[4], (unsigned long long)c_link);
-  }
 }
+#undef VCP_FLUSH
+#undef VCP_JOIN
 
 // flatten + smallest list position per component; lanes of a wave that share a root (the common
 // case inside a blob: the wave covers neighbouring cells) combine before one atomicMin
@@ -733,26 +912,28 @@ __global__ __launch_bounds__(TPB) void k_border(const double* __restrict__ sorte
       int cc[3];
       load_pt<GD>(sorted, p, q);
       cell_of<GD>(q, g, cc);
-      constexpr int UNR = GD == 3 ? VCP_UNR3 : VCP_UNR2;
+      constexpr int UNR = VCP_UNRW;
       const int32_t myg = GROUPED ? sgroup[p] : 0;
       uint32_t mx = 0, mnk = NONE;
+      // The cluster rank of a candidate is read FIRST (4 B; NONE = not expanding): a border point sits mostly
+      // among non-expanding points, and once some cluster is known to reach it, further members of clusters
+      // ranked between the current min and max cannot change the result -- only the remaining candidates pay
+      // for the coordinate load and the binary64 test.
       for_rows<GD>(cc, g, cellstart, [&](uint32_t s, uint32_t e) {
         for (uint32_t j0 = s; j0 < e; j0 += UNR) {
-          double rr[UNR][3];
-          bool cand[UNR];
+          uint32_t rk[UNR];
+#pragma unroll
+          for (int u = 0; u < UNR; u++) rk[u] = rootk[min(j0 + u, e - 1)];
 #pragma unroll
           for (int u = 0; u < UNR; u++) {
-            const uint32_t jj = min(j0 + u, e - 1);
-            cand[u] = (j0 + u < e) && (flags[jj] & F_EXPAND);
-            if (GROUPED) cand[u] = cand[u] && sgroup[jj] == myg;
-            load_pt<GD>(sorted, jj, rr[u]);
-          }
-#pragma unroll
-          for (int u = 0; u < UNR; u++) {
-            if (cand[u] && within<METRIC>(q, rr[u], thr)) {
-              uint32_t k = rootk[parent[j0 + u]];
-              mx = max(mx, k + 1u);
-              mnk = min(mnk, k);
+            const uint32_t j = j0 + u, x = rk[u];
+            if (j >= e || x == NONE || (x >= mnk && x < mx)) continue;
+            if (GROUPED && sgroup[j] != myg) continue;
+            double rr[3];
+            load_pt<GD>(sorted, j, rr);
+            if (within<METRIC>(q, rr, thr)) {
+              mx = max(mx, x + 1u);
+              mnk = min(mnk, x);
             }
           }
         }
@@ -776,14 +957,24 @@ __global__ __launch_bounds__(TPB) void k_border(const double* __restrict__ sorte
 // labk of every position the border list does not cover: expanding points take their component's rank,
 // everything else (no neighbour within eps) keeps 0
 __global__ __launch_bounds__(TPB) void k_labk_rest(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ parent,
-                                                  const uint32_t* __restrict__ rootk, uint32_t* __restrict__ labk,
+                                                  uint32_t* rootk, uint32_t* __restrict__ labk,
                                                   const uint32_t* __restrict__ cellstart, uint32_t ncells) {
   const uint32_t nin = cellstart[ncells];
   int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
   if (p >= nin) return;
   const uint8_t fl = flags[p];
+  // rootk is defined at roots (k_rootk); extend it to every position -- the seed rank of the point's cluster,
+  // NONE for points that are not expanding -- so that the border search needs one load per candidate
+  uint32_t k = NONE;
+  if (fl & F_EXPAND) {
+    const uint32_t r = parent[p];
+    k = rootk[r];
+    if (r != (uint32_t)p) rootk[p] = k;
+  } else {
+    rootk[p] = NONE;
+  }
   if (fl & F_BCAND) return;
-  const uint32_t out = (fl & F_EXPAND) ? rootk[parent[p]] + 1u : 0u;
+  const uint32_t out = (fl & F_EXPAND) ? k + 1u : 0u;
   labk[p] = (out << 2) | ((fl & F_CORE) ? 1u : 0u) | ((fl & F_CLASSED) ? 2u : 0u);
 }
 
@@ -1154,38 +1345,29 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   wlE.perblk = wlB.perblk = (nb + 7) / 8;
   VCP_HIP(ctx, hipMemsetAsync(blkE, 0, (size_t)(nb + 2) * 2 * 4, st));
   const unsigned nbl = 8u * wlE.perblk;  // list kernels: block b -> region b & 7 (a region has <= perblk*TPB entries)
-  hipLaunchKernelGGL((k_core<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 0, st, sorted, g, thr, min_pts, cellcnt, sgroup,
-                     flags, blkE, blkB);
+  if constexpr (GD == 2 && !GROUPED)
+    hipLaunchKernelGGL((k_core_lds<METRIC>), dim3(nb), dim3(TPB), 0, st, sorted, g, thr, min_pts, cellcnt, flags, blkE,
+                       blkB);
+  else
+    hipLaunchKernelGGL((k_core<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 0, st, sorted, g, thr, min_pts, cellcnt, sgroup,
+                       flags, blkE, blkB);
   VCP_TRY(vcp_exclusive_scan_u32(ctx, blkE, blkE, (int64_t)nb + 1, nullptr));
   VCP_TRY(vcp_exclusive_scan_u32(ctx, blkB, blkB, (int64_t)nb + 1, nullptr));
   hipLaunchKernelGGL(k_wl_fill, dim3(nb), dim3(TPB), 0, st, flags, cellcnt, g.ncells, blkE, blkB, wlE.list, wlB.list);
 
   // 6. components of the expanding points
   vcp_phase(ctx, "union");
-  hipLaunchKernelGGL(k_init_parent, dim3(nb), dim3(TPB), 0, st, parent, minord, cellcnt, g.ncells);
+  hipLaunchKernelGGL(k_init_parent, dim3(nb), dim3(TPB), 0, st, parent, minord, flags, cellcnt, g.ncells);
   VCP_HIP(ctx, hipMemsetAsync(seedflag, 0, (size_t)nw * 4, st));
   VCP_HIP(ctx, hipMemsetAsync(counters, 0, 36 * sizeof(unsigned long long), st));
-  const int dbg = getenv("VCP_DBG_UNION") ? atoi(getenv("VCP_DBG_UNION")) : 0;
-  // phases 1-2 pay for their extra search pass in 2-D (3 rows); in 3-D (9 rows) they do not
-  if (GD == 2 && dbg != 4) {
+  // phases 1-2 pay for their extra search pass in 2-D (3 rows); in 3-D (9 rows) they do not (measured: +28 %)
+  if (GD == 2) {
     hipLaunchKernelGGL((k_union_init<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup,
                        flags, parent, wlE);
     hipLaunchKernelGGL(k_flatten0, dim3(nb), dim3(TPB), 0, st, parent, flags, cellcnt, g.ncells);
-    const int rounds = getenv("VCP_UNION_ROUNDS") ? atoi(getenv("VCP_UNION_ROUNDS")) : 0;
-    for (int r = 0; r < rounds; r++) {
-      hipLaunchKernelGGL((k_root_hook<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup,
-                         flags, parent, wlE);
-      hipLaunchKernelGGL(k_flatten0, dim3(nb), dim3(TPB), 0, st, parent, flags, cellcnt, g.ncells);
-    }
   }
-  hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup, flags,
-                     parent, dbg, wlE, counters + 8);
-  if (dbg == 5) {
-    unsigned long long hd[5];
-    VCP_HIP(ctx, hipMemcpyAsync(hd, counters + 8, sizeof(hd), hipMemcpyDeviceToHost, st));
-    VCP_HIP(ctx, hipStreamSynchronize(st));
-    fprintf(stderr, "[union] edges %llu fast1 %llu fast2 %llu slow %llu links %llu\n", hd[0], hd[1], hd[2], hd[3], hd[4]);
-  }
+  hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED, GD == 2>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup,
+                     parent, wlE);
   vcp_phase(ctx, "flatten_number");
   hipLaunchKernelGGL(k_flatten, dim3(nb), dim3(TPB), 0, st, parent, flags, sord, minord, cellcnt, g.ncells);
   if (!GROUPED && ext && ext->slab) {

@@ -310,13 +310,20 @@ __device__ __forceinline__ void row_bounds(const int* cc, const GridP& g, const 
 }
 
 // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  The neighbour-search kernels
-// remap the block index so that each XCD walks ONE contiguous eighth of the cell-ordered arrays: a point's
-// neighbour rows are then (mostly) in its own XCD's 4 MiB L2.  Speed only, never correctness.
+// remap the block index so that each XCD walks contiguous bands of the cell-ordered arrays: a point's
+// neighbour rows are then (mostly) in its own XCD's 4 MiB L2.  The array is cut into 8*XCHUNK bands dealt
+// round-robin to the XCDs, so that dense and sparse parts of the cloud are spread over all of them (with one
+// band per XCD the slowest XCD set the kernel time).  Speed only, never correctness.
+constexpr unsigned XCHUNK = 8;
+// bands per XCD for the work-list kernels: 1.  More bands cost the union-find kernels 20-35 % (more trees
+// straddle two XCDs' L2s); the border search is indifferent.
+constexpr unsigned LCHUNK = 1;
 __device__ __forceinline__ int64_t xcd_block(unsigned nblocks) {
   const unsigned b = blockIdx.x;
-  const unsigned per = nblocks >> 3;  // blocks per XCD in the remapped part
-  if (b >= (per << 3)) return b;      // tail blocks keep their index
-  return (int64_t)(b & 7u) * per + (b >> 3);
+  const unsigned per = nblocks / (8u * XCHUNK);  // blocks per chunk in the remapped part
+  if (b >= per * 8u * XCHUNK) return b;          // tail blocks keep their index
+  const unsigned x = b & 7u, i = b >> 3;         // XCD, and this block's turn on it
+  return (int64_t)((i / per) * 8u + x) * per + (i % per);
 }
 
 // Work lists.  Only ~1/4 of the points are expanding and only the non-core points that have a neighbour
@@ -327,19 +334,21 @@ __device__ __forceinline__ int64_t xcd_block(unsigned nblocks) {
 struct WorkList {
   uint32_t* list;        // positions, in position order
   const uint32_t* scan;  // [nblk+1] exclusive scan of the per-block entry counts (blocks of TPB positions)
-  uint32_t perblk;       // blocks per region
+  uint32_t perblk;       // workgroups per band of the list
   uint32_t nblk;
 };
 
-// position handled by this thread of a list kernel, or NONE.  Block b works in eighth (b & 7) of the LIST
-// (equal entry counts per XCD; eighths of the position range were up to 34 % apart in entries on the C4
-// cloud, and the slowest XCD sets the kernel time).  The list is in position order, so an eighth is still one
-// contiguous band of the cell-ordered arrays.
+// position handled by this thread of a list kernel, or NONE.  The LIST is cut into 8*LCHUNK bands of equal
+// entry counts, dealt round-robin to the XCDs like the position bands of xcd_block (eighths of the position
+// range were up to 34 % apart in entries on the C4 cloud).  The list is in position order, so a band of the
+// list is still one contiguous band of the cell-ordered arrays.  perblk = workgroups per band.
 __device__ __forceinline__ uint32_t wl_fetch(const WorkList& w) {
   const uint32_t total = w.scan[w.nblk];
-  const uint32_t r = blockIdx.x & 7u;
-  const uint32_t lo = (uint32_t)(((uint64_t)total * r) >> 3), hi = (uint32_t)(((uint64_t)total * (r + 1u)) >> 3);
-  const uint32_t t = lo + (blockIdx.x >> 3) * TPB + threadIdx.x;
+  const uint32_t x = blockIdx.x & 7u, i = blockIdx.x >> 3;
+  const uint32_t c = (i / w.perblk) * 8u + x;  // band
+  const uint32_t lo = (uint32_t)(((uint64_t)total * c) / (8u * LCHUNK));
+  const uint32_t hi = (uint32_t)(((uint64_t)total * (c + 1u)) / (8u * LCHUNK));
+  const uint32_t t = lo + (i % w.perblk) * TPB + threadIdx.x;
   if (t >= hi) return NONE;
   return w.list[t];
 }
@@ -1189,6 +1198,12 @@ double l2_threshold(double eps) {
   return t;
 }
 
+// workgroups per band of a work list: a band holds at most ceil(n / (8*LCHUNK)) entries
+unsigned list_perblk(int64_t n) {
+  const int64_t band = (n + 8 * LCHUNK - 1) / (8 * LCHUNK) + 1;
+  return (unsigned)((band + TPB - 1) / TPB);
+}
+
 // GD = dimension of the metric (grid and sorted copy); `stride` = doubles per input point
 template <int GD, int METRIC, bool GROUPED>
 int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, double eps, int min_pts, int32_t cf_in,
@@ -1342,9 +1357,9 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   wlE.scan = blkE;
   wlB.scan = blkB;
   wlE.nblk = wlB.nblk = nb;
-  wlE.perblk = wlB.perblk = (nb + 7) / 8;
+  wlE.perblk = wlB.perblk = list_perblk(n);
   VCP_HIP(ctx, hipMemsetAsync(blkE, 0, (size_t)(nb + 2) * 2 * 4, st));
-  const unsigned nbl = 8u * wlE.perblk;  // list kernels: block b -> region b & 7 (a region has <= perblk*TPB entries)
+  const unsigned nbl = 8u * LCHUNK * wlE.perblk;  // list kernels: see wl_fetch
   if constexpr (GD == 2 && !GROUPED)
     hipLaunchKernelGGL((k_core_lds<METRIC>), dim3(nb), dim3(TPB), 0, st, sorted, g, thr, min_pts, cellcnt, flags, blkE,
                        blkB);
@@ -1456,8 +1471,8 @@ int run_slab_finish(vcp_ctx* ctx, const SlabState& ss, const uint32_t* d_map_rep
   wlB.list = blkB + (nb + 2) + n;
   wlB.scan = blkB;
   wlB.nblk = nb;
-  wlB.perblk = (nb + 7) / 8;
-  const unsigned nbl = 8u * wlB.perblk;
+  wlB.perblk = list_perblk(n);
+  const unsigned nbl = 8u * LCHUNK * wlB.perblk;
   const int rb = (int)vcp_blocks(n, TPB, 1024);
   unsigned long long* counters = reinterpret_cast<unsigned long long*>(ctx->b_misc.as<double>() + (size_t)rb * 8 + 8);
   vcp_phase(ctx, "slab_roots");

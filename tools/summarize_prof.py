@@ -18,18 +18,21 @@ import sys
 from collections import defaultdict
 
 PHASE_OF = {
-    "k_bounds": "bounds", "k_bounds_final": "bounds", "k_cell_hist": "cell_hist", "k_scatter": "scatter",
+    "k_bounds": "bounds", "k_bounds_final": "bounds", "k_cell_key": "cell_key", "rocprim_radix_sort": "cell_sort",
+    "k_mark_ends": "cell_scan", "k_gather": "scatter",
     "k_scan_tile_sums": "cell_scan", "k_scan_offsets": "cell_scan", "k_scan_tiles": "cell_scan",
-    "k_core": "core_count", "k_wl_fill": "core_count",
+    "k_core": "core_count", "k_core_lds": "core_count", "k_wl_fill": "core_count",
     "k_union": "union", "k_union_init": "union", "k_flatten0": "union", "k_init_parent": "union",
     "k_flatten": "flatten_number", "k_seed_popc": "flatten_number", "k_seedflag": "flatten_number",
-    "k_rootk": "flatten_number", "k_labk_rest": "flatten_number",
-    "k_border": "border", "k_output": "output",
+    "k_rootk": "flatten_number",
+    "k_labk_rest": "border", "k_border": "border", "k_output": "output",
     "k_icp_pass": "icp", "k_icp_step": "icp", "k_model32": "icp", "k_absmax": "icp",
 }
 
 
 def short(name):
+    if "rocprim" in name and ("radix" in name or "onesweep" in name or "histogram" in name):
+        return "rocprim_radix_sort"
     m = re.search(r"(k_[a-z0-9_]+)", name)
     return m.group(1) if m else name.split("(")[0][:60]
 

@@ -6,23 +6,29 @@
 // conservative by construction (cell edge = eps * (1 + 2^-20), candidates re-tested exactly).
 //
 // Data layout in HBM (n points, original index i, sorted position p, GD = dimension of the metric):
-//   cellcnt [ncells+1] u32   histogram, then exclusive scan = first sorted position of each cell
-//   cellof  [n] u32, rank [n] u32   cell id / arrival rank inside the cell, by original index
+//   cellof  [n] u32, skey [n] u32   cell id by original index / in cell order (rocPRIM radix sort of
+//                            (cell id, index) pairs; points excluded from a grouped call sort last)
+//   cellcnt [ncells+1] u32   first sorted position of each cell (marks of the cell ends, exclusive max-scan)
 //   pos     [n] u32          sorted position of original index i (NONE = excluded from this call)
 //   sorted  [nin*GD] f64     coordinates in cell order (x-fastest linear cell id)
 //   sord    [nin] u32        "list position" of the point (original index, or the caller's ord)
 //   sgroup  [nin] i32        group (block) of the point, grouped calls only
-//   flags   [nin] u8         bit0 core, bit1 classed on entry, bit2 expanding
-//   parent  [nin] u32        union-find over sorted positions (pointers only decrease)
+//   flags   [nin] u8         bit0 core, bit1 classed on entry, bit2 expanding, bit3 border candidate
+//   wlE, wlB                 position-ordered work lists: expanding points; non-core points with a neighbour
+//   parent  [nin] u32        union-find over sorted positions (pointers only decrease); NONE = not expanding
 //   minord  [nin] u32        per root: smallest list position in the component (= the seed)
-//   seedflag[n+1] u32        1 at the list position of each seed, then its exclusive scan
-//   rootk   [nin] u32        per root: rank of its seed among all seeds; clseed [K]: seed per rank
+//   seedflag[n/32] u32       bitmap of seed list positions; seedpref = popcount prefix per word
+//   rootk   [nin] u32        seed rank of the point's cluster (NONE = not expanding); clseed [K]: seed per rank
 //   labk    [nin] u32        per point: (1 + seed rank of its final cluster, 0 = none) << 2 | core | classed<<1
-// Passes: bounds -> cell_hist -> scan -> scatter -> core -> union -> flatten/number -> border -> output.
+// Passes: bounds -> cell keys -> sort -> cell starts -> gather -> core -> union -> flatten/number -> border -> output.
+#include <string.h>
+
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+
+#include <rocprim/rocprim.hpp>
 
 #include "dbscan_engine.hpp"
 
@@ -214,57 +220,65 @@ __device__ __forceinline__ uint32_t cell_of(const double* q, const GridP& g, int
   return cell_id<GD>(g, cc[0], cc[1], cc[2]);
 }
 
+// ---- sort-based grid build ---------------------------------------------------------------------------
+// Global atomics execute at the memory side on this part (about 20 G scattered adds/s chip-wide), so a
+// histogram with one returned atomic per point costs more than a radix sort of (cell id, point index) pairs,
+// whose counting happens in LDS.  The sort also makes the scatter a gather: reads are random, stores coalesced.
 template <int GD, bool GROUPED>
-__global__ __launch_bounds__(TPB) void k_cell_hist(const double* __restrict__ c, int64_t n, int stride, GridP g,
-                                                  const int32_t* __restrict__ group, int glo, int ghi,
-                                                  uint32_t* __restrict__ cellcnt, uint32_t* __restrict__ cellof,
-                                                  uint32_t* __restrict__ rank) {
+__global__ __launch_bounds__(TPB) void k_cell_key(const double* __restrict__ c, int64_t n, int stride, GridP g,
+                                                 const int32_t* __restrict__ group, int glo, int ghi,
+                                                 uint32_t* __restrict__ key, uint32_t* __restrict__ val,
+                                                 uint32_t* __restrict__ pos) {
   int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
   if (i >= n) return;
+  val[i] = (uint32_t)i;
   if (GROUPED) {
     int gg = group[i];
     if (gg < glo || gg >= ghi) {
-      cellof[i] = NONE;
+      key[i] = g.ncells;  // excluded from this call: sorts behind every cell
+      pos[i] = NONE;
       return;
     }
   }
   double q[3];
   int cc[3];
   load_in<GD>(c, i, stride, q);
-  uint32_t id = cell_of<GD>(q, g, cc);
-  cellof[i] = id;
-  rank[i] = atomicAdd(&cellcnt[id], 1u);
+  key[i] = cell_of<GD>(q, g, cc);
+}
+
+// mark[k] = (last position of cell k) + 1; an exclusive max-scan of the marks is the first position of each cell
+__global__ __launch_bounds__(TPB) void k_mark_ends(const uint32_t* __restrict__ skey, int64_t n, uint32_t ncells,
+                                                  uint32_t* __restrict__ mark) {
+  int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t k = skey[p];
+  if (k >= ncells) return;
+  if (p == n - 1 || skey[p + 1] != k) mark[k] = (uint32_t)p + 1u;
 }
 
 template <int GD, bool GROUPED>
-__global__ __launch_bounds__(TPB) void k_scatter(const double* __restrict__ c, int64_t n, int stride,
-                                                const uint32_t* __restrict__ cellstart,
-                                                const uint32_t* __restrict__ cellof,
-                                                const uint32_t* __restrict__ rank,
-                                                const uint8_t* __restrict__ in_classed,
-                                                const int32_t* __restrict__ group, const uint32_t* __restrict__ ord,
-                                                uint32_t* __restrict__ pos, double* __restrict__ sorted,
-                                                uint32_t* __restrict__ sord, int32_t* __restrict__ sgroup,
-                                                uint8_t* __restrict__ flags) {
-  int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
-  if (i >= n) return;
-  uint32_t cid = cellof[i];
-  if (GROUPED && cid == NONE) {
-    pos[i] = NONE;
-    return;
-  }
-  uint32_t p = cellstart[cid] + rank[i];
-  pos[i] = p;
+__global__ __launch_bounds__(TPB) void k_gather(const double* __restrict__ c, int stride,
+                                               const uint32_t* __restrict__ cellstart, uint32_t ncells,
+                                               const uint32_t* __restrict__ sidx, const uint8_t* __restrict__ in_classed,
+                                               const int32_t* __restrict__ group, const uint32_t* __restrict__ ord,
+                                               uint32_t* __restrict__ pos, double* __restrict__ sorted,
+                                               uint32_t* __restrict__ sord, int32_t* __restrict__ sgroup,
+                                               uint8_t* __restrict__ flags) {
+  const uint32_t nin = cellstart[ncells];
+  int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (p >= nin) return;
+  const uint32_t i = sidx[p];
+  pos[i] = (uint32_t)p;
   double q[3];
   load_in<GD>(c, i, stride, q);
   if (GD == 2) {
-    *reinterpret_cast<double2*>(sorted + 2 * (int64_t)p) = make_double2(q[0], q[1]);
+    *reinterpret_cast<double2*>(sorted + 2 * p) = make_double2(q[0], q[1]);
   } else {
-    sorted[3 * (int64_t)p] = q[0];
-    sorted[3 * (int64_t)p + 1] = q[1];
-    sorted[3 * (int64_t)p + 2] = q[2];
+    sorted[3 * p] = q[0];
+    sorted[3 * p + 1] = q[1];
+    sorted[3 * p + 2] = q[2];
   }
-  sord[p] = ord ? ord[i] : (uint32_t)i;
+  if (ord) sord[p] = ord[i];  // otherwise sidx IS sord (the sort wrote it there)
   if (GROUPED) sgroup[p] = group[i];
   if (in_classed) flags[p] = in_classed[i] ? F_CLASSED : 0;  // otherwise flags were zero-filled
 }
@@ -609,11 +623,14 @@ __device__ __forceinline__ uint32_t ld_parent_cached(const uint32_t* parent, uin
   return __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
+#ifndef VCP_ROOT_CACHED
+#define VCP_ROOT_CACHED 1
+#endif
 __device__ __forceinline__ uint32_t uf_root(const uint32_t* parent, uint32_t x) {
-  uint32_t p = ld_parent(parent, x);
+  uint32_t p = VCP_ROOT_CACHED ? ld_parent_cached(parent, x) : ld_parent(parent, x);
   while (p != x) {
     x = p;
-    p = ld_parent(parent, x);
+    p = VCP_ROOT_CACHED ? ld_parent_cached(parent, x) : ld_parent(parent, x);
   }
   return x;
 }
@@ -802,7 +819,7 @@ __global__ __launch_bounds__(TPB) void k_union(const double* __restrict__ sorted
         if (!hit) continue;
         if (!PRE) {
           // second hop: j's tree was hooked under my root by an earlier edge (one L2 load instead of two chases)
-          const uint32_t x2 = ld_parent(parent, x);
+          const uint32_t x2 = ld_parent_cached(parent, x);
           if (x2 != rp) {
             const uint32_t rx = uf_root(parent, x2);
             const uint32_t rm = uf_root(parent, rp);
@@ -1334,17 +1351,31 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   unsigned long long* counters = reinterpret_cast<unsigned long long*>(d_bounds + 8);
   uint32_t* d_total = reinterpret_cast<uint32_t*>(counters + 2);
 
-  // 4. histogram + ranks, scan, scatter
-  vcp_phase(ctx, "cell_hist");
-  VCP_HIP(ctx, hipMemsetAsync(cellcnt, 0, (size_t)(ncells + 1) * 4, st));
-  hipLaunchKernelGGL((k_cell_hist<GD, GROUPED>), dim3(nb), dim3(TPB), 0, st, d_coords, n, stride, g, d_group, glo, ghi,
-                     cellcnt, cellof, rank);
-  vcp_phase(ctx, "cell_scan");
-  VCP_TRY(vcp_exclusive_scan_u32(ctx, cellcnt, cellcnt, ncells + 1, nullptr));
-  vcp_phase(ctx, "scatter");
-  if (!d_in_classed) VCP_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)n, st));
-  hipLaunchKernelGGL((k_scatter<GD, GROUPED>), dim3(nb), dim3(TPB), 0, st, d_coords, n, stride, cellcnt, cellof, rank,
-                     d_in_classed, d_group, d_ord, pos, sorted, sord, sgroup, flags);
+  // 4. cell order: sort (cell id, index) pairs, cell starts from the sorted keys, gather
+  {
+    vcp_phase(ctx, "cell_key");
+    VCP_TRY(vcp_ensure(ctx, ctx->b_skey, (size_t)n * 4));
+    uint32_t* skey = ctx->b_skey.as<uint32_t>();
+    uint32_t* sidx = d_ord ? rank : sord;  // without a caller ord the sorted index is the list position itself
+    hipLaunchKernelGGL((k_cell_key<GD, GROUPED>), dim3(nb), dim3(TPB), 0, st, d_coords, n, stride, g, d_group, glo, ghi,
+                       cellof, d_ord ? sord : rank, pos);
+    uint32_t* vals_in = d_ord ? sord : rank;
+    vcp_phase(ctx, "cell_sort");
+    int bits = 1;
+    while (bits < 32 && (g.ncells >> bits) != 0) bits++;  // keys go up to ncells (excluded points)
+    size_t tb = 0;
+    VCP_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, cellof, skey, vals_in, sidx, (size_t)n, 0, bits, st));
+    VCP_TRY(vcp_ensure(ctx, ctx->b_sorttmp, tb));
+    VCP_HIP(ctx, rocprim::radix_sort_pairs(ctx->b_sorttmp.p, tb, cellof, skey, vals_in, sidx, (size_t)n, 0, bits, st));
+    vcp_phase(ctx, "cell_scan");
+    VCP_HIP(ctx, hipMemsetAsync(cellcnt, 0, (size_t)(ncells + 1) * 4, st));
+    hipLaunchKernelGGL(k_mark_ends, dim3(nb), dim3(TPB), 0, st, skey, n, g.ncells, cellcnt);
+    VCP_TRY(vcp_exclusive_max_scan_u32(ctx, cellcnt, cellcnt, ncells + 1, nullptr));
+    vcp_phase(ctx, "scatter");
+    if (!d_in_classed) VCP_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)n, st));
+    hipLaunchKernelGGL((k_gather<GD, GROUPED>), dim3(nb), dim3(TPB), 0, st, d_coords, stride, cellcnt, g.ncells, sidx,
+                       d_in_classed, d_group, d_ord, pos, sorted, sord, sgroup, flags);
+  }
 
   // 5. core flags + work lists (expanding points; non-core points that have a neighbour)
   vcp_phase(ctx, "core_count");

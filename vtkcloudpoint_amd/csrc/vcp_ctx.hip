@@ -85,31 +85,42 @@ constexpr int ST = 256;            // threads
 constexpr int SCH = 8;             // chunks per tile
 constexpr int STILE = ST * 4 * SCH;  // 8192 elements per tile
 
+// the scan operator: sum, or max (identity 0 for both)
+template <bool MX>
+__device__ __forceinline__ uint32_t sop(uint32_t a, uint32_t b) {
+  return MX ? max(a, b) : a + b;
+}
+
+template <bool MX>
 __device__ __forceinline__ uint32_t wave_incl(uint32_t v, int lane) {
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     uint32_t t = __shfl_up(v, d, 64);
-    if (lane >= d) v += t;
+    if (lane >= d) v = sop<MX>(v, t);
   }
   return v;
 }
 
-// block-wide exclusive scan of one value per thread; *total = block sum.  Two barriers.
+// block-wide exclusive scan of one value per thread; *total = block sum (max).  Two barriers.
+template <bool MX>
 __device__ __forceinline__ uint32_t block_excl(uint32_t v, uint32_t* total, uint32_t* sm /*[ST/64 + 1]*/) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const uint32_t inc = wave_incl(v, lane);
+  const uint32_t inc = wave_incl<MX>(v, lane);
   if (lane == 63) sm[w] = inc;
   __syncthreads();
   uint32_t base = 0, tot = 0;
 #pragma unroll
   for (int k = 0; k < ST / 64; k++) {
     const uint32_t x = sm[k];
-    if (k < w) base += x;
-    tot += x;
+    if (k < w) base = sop<MX>(base, x);
+    tot = sop<MX>(tot, x);
   }
   __syncthreads();
   *total = tot;
-  return base + inc - v;
+  // exclusive value of this thread: everything before it in its wave, plus the earlier waves
+  uint32_t prev = __shfl_up(inc, 1, 64);
+  if (lane == 0) prev = 0;
+  return sop<MX>(base, prev);
 }
 
 template <bool VEC>
@@ -123,7 +134,7 @@ __device__ __forceinline__ uint4 ld4(const uint32_t* __restrict__ in, int64_t i,
   return v;
 }
 
-template <bool VEC>
+template <bool VEC, bool MX>
 __global__ __launch_bounds__(ST) void k_scan_tile_sums(const uint32_t* __restrict__ in, int64_t n,
                                                       uint32_t* __restrict__ tsum) {
   const int64_t base = (int64_t)blockIdx.x * STILE;
@@ -131,32 +142,33 @@ __global__ __launch_bounds__(ST) void k_scan_tile_sums(const uint32_t* __restric
 #pragma unroll
   for (int k = 0; k < SCH; k++) {
     const uint4 v = ld4<VEC>(in, base + ((int64_t)k * ST + threadIdx.x) * 4, n);
-    s += v.x + v.y + v.z + v.w;
+    s = sop<MX>(s, sop<MX>(sop<MX>(v.x, v.y), sop<MX>(v.z, v.w)));
   }
   __shared__ uint32_t sm[ST / 64 + 1];
   uint32_t tot;
-  block_excl(s, &tot, sm);
+  block_excl<MX>(s, &tot, sm);
   if (threadIdx.x == 0) tsum[blockIdx.x] = tot;
 }
 
 // single workgroup: exclusive scan of nt tile sums in place; thread t owns a contiguous run
+template <bool MX>
 __global__ __launch_bounds__(ST) void k_scan_offsets(uint32_t* __restrict__ tsum, int nt, uint32_t* __restrict__ total) {
   const int per = (nt + ST - 1) / ST;
   const int lo = min((int)threadIdx.x * per, nt), hi = min(lo + per, nt);
   uint32_t s = 0;
-  for (int i = lo; i < hi; i++) s += tsum[i];
+  for (int i = lo; i < hi; i++) s = sop<MX>(s, tsum[i]);
   __shared__ uint32_t sm[ST / 64 + 1];
   uint32_t tot;
-  uint32_t pre = block_excl(s, &tot, sm);
+  uint32_t pre = block_excl<MX>(s, &tot, sm);
   for (int i = lo; i < hi; i++) {
     const uint32_t v = tsum[i];
     tsum[i] = pre;
-    pre += v;
+    pre = sop<MX>(pre, v);
   }
   if (threadIdx.x == 0 && total) *total = tot;
 }
 
-template <bool VEC>
+template <bool VEC, bool MX>
 __global__ __launch_bounds__(ST) void k_scan_tiles(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int64_t n,
                                                   const uint32_t* __restrict__ toff) {
   const int64_t base = (int64_t)blockIdx.x * STILE;
@@ -167,8 +179,10 @@ __global__ __launch_bounds__(ST) void k_scan_tiles(const uint32_t* __restrict__ 
     const int64_t i = base + ((int64_t)k * ST + threadIdx.x) * 4;
     const uint4 v = ld4<VEC>(in, i, n);
     uint32_t tot;
-    const uint32_t pre = carry + block_excl(v.x + v.y + v.z + v.w, &tot, sm);
-    const uint4 o = make_uint4(pre, pre + v.x, pre + v.x + v.y, pre + v.x + v.y + v.z);
+    const uint32_t pre =
+        sop<MX>(carry, block_excl<MX>(sop<MX>(sop<MX>(v.x, v.y), sop<MX>(v.z, v.w)), &tot, sm));
+    const uint32_t o1 = sop<MX>(pre, v.x), o2 = sop<MX>(o1, v.y), o3 = sop<MX>(o2, v.z);
+    const uint4 o = make_uint4(pre, o1, o2, o3);
     if (VEC && i + 3 < n) {
       *reinterpret_cast<uint4*>(out + i) = o;
     } else {
@@ -177,13 +191,13 @@ __global__ __launch_bounds__(ST) void k_scan_tiles(const uint32_t* __restrict__ 
       if (i + 2 < n) out[i + 2] = o.z;
       if (i + 3 < n) out[i + 3] = o.w;
     }
-    carry += tot;
+    carry = sop<MX>(carry, tot);
   }
 }
 }  // namespace
 
-int vcp_exclusive_scan_u32(vcp_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, int64_t n,
-                           uint32_t* d_total) {
+template <bool MX>
+static int scan_u32(vcp_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, int64_t n, uint32_t* d_total) {
   if (n <= 0) {
     if (d_total) VCP_HIP(ctx, hipMemsetAsync(d_total, 0, 4, ctx->stream));
     return VCP_OK;
@@ -193,13 +207,22 @@ int vcp_exclusive_scan_u32(vcp_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, 
   uint32_t* tsum = ctx->b_scan_tmp.as<uint32_t>();
   const bool vec = (((uintptr_t)d_in | (uintptr_t)d_out) & 15u) == 0;
   hipStream_t st = ctx->stream;
-  if (vec) hipLaunchKernelGGL(k_scan_tile_sums<true>, dim3((unsigned)nt), dim3(ST), 0, st, d_in, n, tsum);
-  else hipLaunchKernelGGL(k_scan_tile_sums<false>, dim3((unsigned)nt), dim3(ST), 0, st, d_in, n, tsum);
-  hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(ST), 0, st, tsum, (int)nt, d_total);
-  if (vec) hipLaunchKernelGGL(k_scan_tiles<true>, dim3((unsigned)nt), dim3(ST), 0, st, d_in, d_out, n, tsum);
-  else hipLaunchKernelGGL(k_scan_tiles<false>, dim3((unsigned)nt), dim3(ST), 0, st, d_in, d_out, n, tsum);
+  if (vec) hipLaunchKernelGGL((k_scan_tile_sums<true, MX>), dim3((unsigned)nt), dim3(ST), 0, st, d_in, n, tsum);
+  else hipLaunchKernelGGL((k_scan_tile_sums<false, MX>), dim3((unsigned)nt), dim3(ST), 0, st, d_in, n, tsum);
+  hipLaunchKernelGGL(k_scan_offsets<MX>, dim3(1), dim3(ST), 0, st, tsum, (int)nt, d_total);
+  if (vec) hipLaunchKernelGGL((k_scan_tiles<true, MX>), dim3((unsigned)nt), dim3(ST), 0, st, d_in, d_out, n, tsum);
+  else hipLaunchKernelGGL((k_scan_tiles<false, MX>), dim3((unsigned)nt), dim3(ST), 0, st, d_in, d_out, n, tsum);
   VCP_HIP(ctx, hipGetLastError());
   return VCP_OK;
+}
+
+int vcp_exclusive_scan_u32(vcp_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, int64_t n, uint32_t* d_total) {
+  return scan_u32<false>(ctx, d_in, d_out, n, d_total);
+}
+
+// out[i] = max(in[0..i-1]), 0 for i = 0
+int vcp_exclusive_max_scan_u32(vcp_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, int64_t n, uint32_t* d_total) {
+  return scan_u32<true>(ctx, d_in, d_out, n, d_total);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -36,7 +36,7 @@ struct vcp_ctx {
   std::vector<DevBuf*> bufs;
   DevBuf b_cellcnt, b_cellof, b_rank, b_sorted, b_sidx, b_flags, b_parent, b_minord, b_seedflag,
       b_rootcl, b_clseed, b_scan_tmp, b_misc, b_in0, b_in1, b_in2, b_in3, b_out0, b_out1, b_out2,
-      b_out3, b_icp_part, b_aux0, b_aux1, b_aux2, b_aux3, b_aux4, b_aux5, b_pos, b_labk, b_sgroup, b_wl;
+      b_out3, b_icp_part, b_aux0, b_aux1, b_aux2, b_aux3, b_aux4, b_aux5, b_pos, b_labk, b_sgroup, b_wl, b_skey, b_sorttmp;
   struct BlocksState* blocks = nullptr;  // staged block-partitioned pipeline (blocks.hip)
   struct SlabState* slab = nullptr;      // staged exact multi-GPU DBSCAN (dbscan.hip: vcp_slab_*)
   // timing
@@ -82,4 +82,6 @@ static inline unsigned vcp_blocks(int64_t n, int per_block, int cap = 1 << 30) {
 // exclusive scan of n uint32 (in place allowed: out may equal in); writes the grand total to
 // d_total (device uint32) if non-null.  Defined in scan.hip.
 int vcp_exclusive_scan_u32(vcp_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, int64_t n,
+                           uint32_t* d_total);
+int vcp_exclusive_max_scan_u32(vcp_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, int64_t n,
                            uint32_t* d_total);

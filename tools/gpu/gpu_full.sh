@@ -1,0 +1,4 @@
+#!/bin/bash
+set -e
+mkdir -p gpurun_out
+timeout -k 10 1100 python -m pytest tests -x -q -m gpu 2>&1 | tail -4

@@ -272,6 +272,21 @@ def main():
             icp[tag] = {"rounds": r["iters"], "ms": best * 1e3, "rounds_per_s": r["iters"] / best,
                         "rmse": r["rmse"]}
         out["icp_1M_vs_100"] = icp
+        # the reference's production form: block-partitioned pipeline at its defaults (FrmMain.cs:1214-1544),
+        # device-resident, staged API; only for the 2-D motor metric
+        if metric_id == N.L1_2D:
+            local = torch.zeros(n, dtype=torch.int32, device=dev)
+            best = None
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                info = ctx.blocks_begin(None, 0.07, 7, 200, 3, device_ptr=d_coords.data_ptr(), n=n)
+                evb = ctx.blocks_cluster_dev(0, info["nblocks"], local.data_ptr())
+                fin = ctx.blocks_finish_dev(local.data_ptr(), evb, d_labels.data_ptr())
+                e = time.perf_counter() - t1
+                best = e if best is None else min(best, e)
+            out["block_pipeline"] = {"ms": best * 1e3, "Mpoints_per_s": n / best / 1e6, "blocks": info["nblocks"],
+                                     "clusters": fin["cluster_amount"], "eps": 0.07, "min_pts": 7, "pts_in_cell": 200}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cloud, coords, eps, min_pts, metric_id)

@@ -105,3 +105,21 @@ def test_whole_cloud_inside_one_eps_ball(vcp_ctx, oracle):
     big = rng.random((1_000_000, 2))
     g = vcp_ctx.dbscan(big, float("inf"), 10)
     assert g["cf"] == 1 and (g["labels"] == 1).all() and g["evals"] == (1_000_000 + 1) * 1_000_000
+
+
+@pytest.mark.parametrize("metric", [N.L1_2D, N.L2_2D])
+def test_dense_cells_exceed_the_lds_tile(vcp_ctx, oracle, metric):
+    """Hundreds of points per cell: the staged candidate rows of a workgroup do not fit the LDS tile and the
+    core count falls back to the global-memory loop; mixed with sparse parts where the tile path runs, and with
+    pre-classed points."""
+    rng = np.random.default_rng(70 + metric)
+    dense = np.round(rng.uniform(0, 2.0, (30_000, 2)) * 256) / 256     # ~75 points per eps-cell row of 3
+    sparse = np.round(rng.uniform(0, 60.0, (30_000, 2)) * 256) / 256
+    c = np.concatenate([dense, sparse])[rng.permutation(60_000)]
+    cls = (rng.random(len(c)) < 0.05).astype(np.uint8)
+    lab0 = (cls * 9).astype(np.int32)
+    for kw in (dict(), dict(cf_in=2, in_classed=cls, labels=lab0)):
+        o = oracle.dbscan(c, 0.1, 12, metric, kw.get("cf_in", 0), kw.get("in_classed"), kw.get("labels"))
+        g = vcp_ctx.dbscan(c, 0.1, 12, metric, **kw)
+        _same(g, o)
+        assert np.array_equal(g["is_core"], o["is_key"])

@@ -258,14 +258,22 @@ __global__ __launch_bounds__(BT) void k_block_of(const double* __restrict__ moto
 
 // keys for the block-major list: block id of raw[t] (dropped -> nblocks), values raw[t]
 __global__ __launch_bounds__(BT) void k_blockkey(const uint32_t* __restrict__ raw, const int32_t* __restrict__ blockof,
-                                                int64_t n, uint32_t nblocks, uint32_t* __restrict__ key,
-                                                uint32_t* __restrict__ cnt) {
+                                                int64_t n, uint32_t nblocks, uint32_t* __restrict__ key) {
   int64_t t = (int64_t)blockIdx.x * BT + threadIdx.x;
   if (t >= n) return;
   int32_t b = blockof[raw[t]];
-  uint32_t k = b < 0 ? nblocks : (uint32_t)b;
-  key[t] = k;
-  atomicAdd(&cnt[k], 1u);
+  key[t] = b < 0 ? nblocks : (uint32_t)b;
+}
+
+// mark[k] = (last position of key k) + 1 in the sorted key list; an exclusive max-scan of the marks gives the
+// first position of every key (no per-point atomics: global atomics execute at the memory side on this part,
+// and 10 M adds into 27 k counters took 1.6 ms)
+__global__ __launch_bounds__(BT) void k_mark_key_ends(const uint32_t* __restrict__ skey, int64_t n,
+                                                     uint32_t* __restrict__ mark) {
+  int64_t t = (int64_t)blockIdx.x * BT + threadIdx.x;
+  if (t >= n) return;
+  const uint32_t k = skey[t];
+  if (t == n - 1 || skey[t + 1] != k) mark[k] = (uint32_t)t + 1u;
 }
 
 __global__ __launch_bounds__(BT) void k_gather_local(const int32_t* __restrict__ lab_orig, const uint32_t* __restrict__ bl,
@@ -275,23 +283,57 @@ __global__ __launch_bounds__(BT) void k_gather_local(const int32_t* __restrict__
 }
 
 // ---- finish --------------------------------------------------------------------------------------
-// per block: K_b = max local id, Z_b = number of noise points
-__global__ __launch_bounds__(BT) void k_block_stats(const int32_t* __restrict__ local, const uint32_t* __restrict__ blk_t,
-                                                   int64_t m, uint32_t* __restrict__ kb, uint32_t* __restrict__ zb) {
-  int64_t t = (int64_t)blockIdx.x * BT + threadIdx.x;
-  if (t >= m) return;
-  int32_t l = local[t];
-  uint32_t b = blk_t[t];
-  if (l == 0) atomicAdd(&zb[b], 1u);
-  else atomicMax(&kb[b], (uint32_t)l);
+// per block: K_b = max local id, Z_b = number of noise points.  One wave per block walks the block's slice of
+// the block-major label list (coalesced) and reduces in registers: no atomics.
+__global__ __launch_bounds__(BT) void k_block_stats(const int32_t* __restrict__ local, const uint32_t* __restrict__ blockstart,
+                                                   int64_t nblocks, uint32_t* __restrict__ kb, uint32_t* __restrict__ zb) {
+  const int64_t b = (int64_t)blockIdx.x * (BT / 64) + (threadIdx.x >> 6);
+  if (b >= nblocks) return;
+  const int lane = threadIdx.x & 63;
+  uint32_t K = 0, Z = 0;
+  for (uint32_t t = blockstart[b] + lane; t < blockstart[b + 1]; t += 64) {
+    const int32_t l = local[t];
+    if (l == 0) Z++;
+    else K = max(K, (uint32_t)l);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    K = max(K, (uint32_t)__shfl_xor((int)K, d, 64));
+    Z += (uint32_t)__shfl_xor((int)Z, d, 64);
+  }
+  if (lane == 0) {
+    kb[b] = K;
+    zb[b] = Z;
+  }
 }
-__global__ __launch_bounds__(BT) void k_cluster_sizes(const int32_t* __restrict__ local, const uint32_t* __restrict__ blk_t,
-                                                     int64_t m, const uint32_t* __restrict__ cstart,
-                                                     uint32_t* __restrict__ csize) {
-  int64_t t = (int64_t)blockIdx.x * BT + threadIdx.x;
-  if (t >= m) return;
-  int32_t l = local[t];
-  if (l > 0) atomicAdd(&csize[cstart[blk_t[t]] + (uint32_t)l - 1u], 1u);
+// cluster sizes: one wave per block counts its local ids in LDS (a block holds ~ptsInCell points, so few ids);
+// blocks with more ids than the LDS table fall back to global atomics
+constexpr int CS_CAP = 512;
+__global__ __launch_bounds__(BT) void k_cluster_sizes(const int32_t* __restrict__ local, const uint32_t* __restrict__ blockstart,
+                                                     int64_t nblocks, const uint32_t* __restrict__ kb,
+                                                     const uint32_t* __restrict__ cstart, uint32_t* __restrict__ csize) {
+  __shared__ uint32_t cnt[BT / 64][CS_CAP];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * (BT / 64) + w;
+  if (b >= nblocks) return;  // whole waves leave together; no workgroup barrier below
+  const uint32_t K = kb[b];
+  if (K == 0) return;
+  const uint32_t c0 = cstart[b];
+  if (K <= (uint32_t)CS_CAP) {
+    for (uint32_t k = lane; k < K; k += 64) cnt[w][k] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t t = blockstart[b] + lane; t < blockstart[b + 1]; t += 64) {
+      const int32_t l = local[t];
+      if (l > 0) atomicAdd(&cnt[w][l - 1], 1u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t k = lane; k < K; k += 64) csize[c0 + k] = cnt[w][k];
+  } else {
+    for (uint32_t t = blockstart[b] + lane; t < blockstart[b + 1]; t += 64) {
+      const int32_t l = local[t];
+      if (l > 0) atomicAdd(&csize[c0 + (uint32_t)l - 1u], 1u);
+    }
+  }
 }
 // keep[c] for cluster entry c = cstart[b] + k - 1 (FrmMain.cs:1479-1495): a cluster is demoted when the next
 // id shows up and clusLen <= small_max; clusLen over-counts the first cluster of a block without noise by
@@ -332,13 +374,6 @@ __global__ __launch_bounds__(BT) void k_newlab(const int32_t* __restrict__ local
     if (keep[c]) out = (int32_t)keeprank[c] + 1;
   }
   newlab[t] = out;
-}
-__global__ __launch_bounds__(BT) void k_blk_t(const uint32_t* __restrict__ blockstart, int64_t nblocks,
-                                             uint32_t* __restrict__ blk_t) {
-  // one thread per block writes its id over its range (blocks hold ~ptsInCell points)
-  int64_t b = (int64_t)blockIdx.x * BT + threadIdx.x;
-  if (b >= nblocks) return;
-  for (uint32_t t = blockstart[b]; t < blockstart[b + 1]; t++) blk_t[t] = (uint32_t)b;
 }
 __global__ __launch_bounds__(BT) void k_iota(uint32_t* __restrict__ v, int64_t m) {
   int64_t t = (int64_t)blockIdx.x * BT + threadIdx.x;
@@ -469,13 +504,15 @@ int blocks_begin(vcp_ctx* ctx, const double* d_motor_in, bool from_host, const d
   VCP_TRY(ens(ctx, s->bl, (size_t)n * 4));
   VCP_TRY(ens(ctx, s->bpos, (size_t)n * 4));
   uint32_t* bkey = s->tmp2.as<uint32_t>();
-  uint32_t* bkey_out = s->tmp0.as<uint32_t>();
-  VCP_HIP(ctx, hipMemsetAsync(s->blockstart.p, 0, (size_t)(nb1 + 1) * 4, st));
+  VCP_TRY(ens(ctx, s->blk_t, (size_t)(n + 1) * 4));
+  uint32_t* blk_t = s->blk_t.as<uint32_t>();  // block id per block-major position (the sorted keys)
   hipLaunchKernelGGL(k_blockkey, dim3(nblk(n)), dim3(BT), 0, st, s->raw.as<uint32_t>(), s->blockof.as<int32_t>(), n,
-                     (uint32_t)s->nblocks, bkey, s->blockstart.as<uint32_t>());
-  VCP_TRY(sort_pairs(ctx, s, bkey, bkey_out, s->raw.as<uint32_t>(), s->bl.as<uint32_t>(), (size_t)n,
+                     (uint32_t)s->nblocks, bkey);
+  VCP_TRY(sort_pairs(ctx, s, bkey, blk_t, s->raw.as<uint32_t>(), s->bl.as<uint32_t>(), (size_t)n,
                      bits_for((uint64_t)s->nblocks)));
-  VCP_TRY(vcp_exclusive_scan_u32(ctx, s->blockstart.as<uint32_t>(), s->blockstart.as<uint32_t>(), nb1 + 1, nullptr));
+  VCP_HIP(ctx, hipMemsetAsync(s->blockstart.p, 0, (size_t)(nb1 + 1) * 4, st));
+  hipLaunchKernelGGL(k_mark_key_ends, dim3(nblk(n)), dim3(BT), 0, st, blk_t, n, s->blockstart.as<uint32_t>());
+  VCP_TRY(vcp_exclusive_max_scan_u32(ctx, s->blockstart.as<uint32_t>(), s->blockstart.as<uint32_t>(), nb1 + 1, nullptr));
   hipLaunchKernelGGL(k_inverse, dim3(nblk(n)), dim3(BT), 0, st, s->bl.as<uint32_t>(), n, s->bpos.as<uint32_t>());
   VCP_HIP(ctx, hipGetLastError());
   s->h_blockstart.resize((size_t)nb1 + 1);
@@ -527,20 +564,18 @@ int blocks_finish(vcp_ctx* ctx, const int32_t* d_local, int64_t evals_blocks, in
   hipStream_t st = ctx->stream;
   const int64_t n = s->n, m = s->m, nb = s->nblocks;
   const uint32_t* blockstart = s->blockstart.as<uint32_t>();
-  VCP_TRY(ens(ctx, s->blk_t, (size_t)(m + 1) * 4));
   VCP_TRY(ens(ctx, s->kb, (size_t)(nb + 2) * 4));
   VCP_TRY(ens(ctx, s->zb, (size_t)(nb + 2) * 4));
   VCP_TRY(ens(ctx, s->cstart, (size_t)(nb + 2) * 4));
-  uint32_t* blk_t = s->blk_t.as<uint32_t>();
+  const uint32_t* blk_t = s->blk_t.as<uint32_t>();
   uint32_t* kb = s->kb.as<uint32_t>();
   uint32_t* zb = s->zb.as<uint32_t>();
   uint32_t* cstart = s->cstart.as<uint32_t>();
   uint32_t* dmisc = s->misc.as<uint32_t>();  // [0] total clusters, [1] kept, [2] err, [3] Z
+  const unsigned nbw = (unsigned)((nb + BT / 64 - 1) / (BT / 64));  // one wave per block
   VCP_HIP(ctx, hipMemsetAsync(dmisc, 0, 64, st));
-  VCP_HIP(ctx, hipMemsetAsync(kb, 0, (size_t)(nb + 2) * 4, st));
-  VCP_HIP(ctx, hipMemsetAsync(zb, 0, (size_t)(nb + 2) * 4, st));
-  hipLaunchKernelGGL(k_blk_t, dim3(nblk(nb)), dim3(BT), 0, st, blockstart, nb, blk_t);
-  hipLaunchKernelGGL(k_block_stats, dim3(nblk(m)), dim3(BT), 0, st, d_local, blk_t, m, kb, zb);
+  VCP_HIP(ctx, hipMemsetAsync(kb + nb, 0, 8, st));  // the scan reads kb[nb]
+  hipLaunchKernelGGL(k_block_stats, dim3(nbw), dim3(BT), 0, st, d_local, blockstart, nb, kb, zb);
   VCP_TRY(vcp_exclusive_scan_u32(ctx, kb, cstart, nb + 1, dmisc));  // cstart[nb] = total clusters
   uint32_t* hp = reinterpret_cast<uint32_t*>(ctx->pinned);
   VCP_HIP(ctx, hipMemcpyAsync(hp, dmisc, 16, hipMemcpyDeviceToHost, st));
@@ -555,7 +590,7 @@ int blocks_finish(vcp_ctx* ctx, const int32_t* d_local, int64_t evals_blocks, in
   uint32_t* victim_of = s->tmp3.as<uint32_t>();
   VCP_HIP(ctx, hipMemsetAsync(csize, 0, (size_t)(totalC + 2) * 4, st));
   VCP_HIP(ctx, hipMemsetAsync(keep, 0, (size_t)(totalC + 2) * 4 * 2, st));
-  hipLaunchKernelGGL(k_cluster_sizes, dim3(nblk(m)), dim3(BT), 0, st, d_local, blk_t, m, cstart, csize);
+  hipLaunchKernelGGL(k_cluster_sizes, dim3(nbw), dim3(BT), 0, st, d_local, blockstart, nb, kb, cstart, csize);
   hipLaunchKernelGGL(k_keep, dim3(nblk(nb)), dim3(BT), 0, st, nb, cstart, kb, zb, blockstart, csize, s->small_max, keep,
                      victim_of, dmisc + 2);
   VCP_TRY(vcp_exclusive_scan_u32(ctx, keep, keeprank, (int64_t)totalC + 1, dmisc + 1));

@@ -27,8 +27,7 @@ constexpr double DMAX = 1.7976931348623157e308;
 
 __global__ __launch_bounds__(MT) void k_mcc_keys(const int32_t* __restrict__ labels, const int64_t* __restrict__ order,
                                                 int64_t m, int32_t K, uint32_t* __restrict__ keys,
-                                                uint32_t* __restrict__ vals, uint32_t* __restrict__ counts,
-                                                uint32_t* __restrict__ bad) {
+                                                uint32_t* __restrict__ vals, uint32_t* __restrict__ bad) {
   int64_t t = (int64_t)blockIdx.x * MT + threadIdx.x;
   if (t >= m) return;
   int64_t i = order ? order[t] : t;
@@ -39,7 +38,20 @@ __global__ __launch_bounds__(MT) void k_mcc_keys(const int32_t* __restrict__ lab
   }
   keys[t] = (uint32_t)l;
   vals[t] = (uint32_t)i;
-  atomicAdd(&counts[l], 1u);
+}
+
+// segment bounds from the sorted keys (no per-point atomics): mark[l] = (last position of label l) + 1, an
+// exclusive max-scan of the marks is the first position of every label, counts are the differences
+__global__ __launch_bounds__(MT) void k_mcc_mark(const uint32_t* __restrict__ skey, int64_t m, uint32_t* __restrict__ mark) {
+  int64_t t = (int64_t)blockIdx.x * MT + threadIdx.x;
+  if (t >= m) return;
+  const uint32_t k = skey[t];
+  if (t == m - 1 || skey[t + 1] != k) mark[k] = (uint32_t)t + 1u;
+}
+__global__ __launch_bounds__(MT) void k_mcc_counts(const uint32_t* __restrict__ segstart, int32_t K,
+                                                  uint32_t* __restrict__ counts) {
+  int k = blockIdx.x * MT + threadIdx.x;
+  if (k <= K) counts[k] = segstart[k + 1] - segstart[k];
 }
 
 __global__ __launch_bounds__(MT) void k_mcc_gather(const double* __restrict__ xy, const uint32_t* __restrict__ idx,
@@ -338,7 +350,7 @@ extern "C" int vcp_mcc(vcp_ctx* ctx, const double* xy, const int32_t* labels, co
   VCP_HIP(ctx, hipMemsetAsync(counts, 0, (kk + 4) * 4 * 2 + 64, st));
   if (m > 0) {
     hipLaunchKernelGGL(k_mcc_keys, dim3(vcp_blocks(m, MT)), dim3(MT), 0, st, ctx->b_in3.as<int32_t>(),
-                       order ? ctx->b_in2.as<int64_t>() : nullptr, m, K, keys_in, vals_in, counts, bad);
+                       order ? ctx->b_in2.as<int64_t>() : nullptr, m, K, keys_in, vals_in, bad);
     size_t tb = 0;
     const int bits = bits_for_u32((uint64_t)K);
     VCP_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, keys_in, keys_out, vals_in, vals_out, (size_t)m, 0, bits, st));
@@ -347,8 +359,9 @@ extern "C" int vcp_mcc(vcp_ctx* ctx, const double* xy, const int32_t* labels, co
     hipLaunchKernelGGL(k_mcc_gather, dim3(vcp_blocks(m, MT)), dim3(MT), 0, st, ctx->b_in0.as<double>(), vals_out, m,
                        ctx->b_aux4.as<double>());
   }
-  VCP_HIP(ctx, hipMemcpyAsync(segstart, counts, (kk + 2) * 4, hipMemcpyDeviceToDevice, st));
-  VCP_TRY(vcp_exclusive_scan_u32(ctx, segstart, segstart, K + 2, nullptr));
+  if (m > 0) hipLaunchKernelGGL(k_mcc_mark, dim3(vcp_blocks(m, MT)), dim3(MT), 0, st, keys_out, m, segstart);
+  VCP_TRY(vcp_exclusive_max_scan_u32(ctx, segstart, segstart, K + 2, nullptr));  // segstart[K+1] = m
+  hipLaunchKernelGGL(k_mcc_counts, dim3(vcp_blocks(K + 1, MT)), dim3(MT), 0, st, segstart, K, counts);
   hipLaunchKernelGGL(k_mcc, dim3(K), dim3(MT), 0, st, ctx->b_aux4.as<double>(), segstart, counts, ctx->b_aux5.as<uint8_t>(),
                      ctx->b_out0.as<double>(), ctx->b_out2.as<double>(), ctx->b_out1.as<uint8_t>(), ctx->b_out3.as<int32_t>());
   VCP_HIP(ctx, hipGetLastError());

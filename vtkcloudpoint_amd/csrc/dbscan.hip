@@ -342,9 +342,9 @@ __device__ __forceinline__ int64_t xcd_block(unsigned nblocks) {
 
 // Work lists.  Only ~1/4 of the points are expanding and only the non-core points that have a neighbour
 // need the border search; running those kernels over all positions leaves most lanes idle.  k_core therefore
-// appends positions to two compact lists (one wave-aggregated atomic per wave).  Each list is split into 8
-// regions = eighths of the position range, and list kernels map block b to region b & 7: blocks b and b+8
-// share an XCD, so a region's data stays in one XCD's L2.  Append order is arbitrary; no result depends on it.
+// counts, per block of TPB positions, the entries of two lists; an exclusive scan of the counts and k_wl_fill
+// build both lists in position order without any append atomic.  List kernels split a list into bands per XCD
+// (wl_fetch).
 struct WorkList {
   uint32_t* list;        // positions, in position order
   const uint32_t* scan;  // [nblk+1] exclusive scan of the per-block entry counts (blocks of TPB positions)

@@ -39,6 +39,61 @@ namespace vtkPointCloud
             double[] M, double max_dist, double[] matched_xyz, byte[] is_matched, int[] nearest, double[] nearest_dist,
             out int count_matched);
 
+        [DllImport(Lib)] public static extern int vcp_refresh_by_dictionary(IntPtr ctx, double[] xyz, double[] motor,
+            int[] labels, long n, int K, int[] map_by_id, out int new_k, double[] c3, double[] c2, long[] counts);
+
+        [DllImport(Lib)] public static extern int vcp_icp_sums(IntPtr ctx, double[] model, long nm, double[] data, long nd,
+            double[] R, double[] T, double[] sums, int[] nn);
+
+        // MainForm.ICP() (FrmMain.cs:841-907): the knobs it sets on vtkIterativeClosestPointTransform
+        [DllImport(Lib)] public static extern int vcp_icp_vtklike(IntPtr ctx, double[] source, long ns, double[] target,
+            long nt, int max_iter, int max_landmarks, int start_by_matching_centroids, double[] M, out double mean_dist,
+            out int iters);
+
+        // Tools.getCircles / Geometry.FindMinimalBoundingCircle (Tools.cs:394-409, Geometry.cs:247-319)
+        [DllImport(Lib)] public static extern int vcp_mcc(IntPtr ctx, double[] xy, int[] labels, long[] order, long m, long n,
+            int K, double[] centers, double[] radius, byte[] valid, int[] hull_n);
+
+        // per-row work of MainForm.AddFolder (FrmMain.cs:1011-1090)
+        [DllImport(Lib)] public static extern int vcp_import_convert(IntPtr ctx, double[] rows, long n, double x_angle,
+            double y_angle, int xdir, int ydir, int dedupe, double[] xyz, byte[] state, out long kept, out long duplicates);
+
+        // query of MainForm.refreshClusList (FrmMain.cs:3452-3456)
+        [DllImport(Lib)] public static extern int vcp_assign_truths(IntPtr ctx, double[] motor, long n, double[] truths_xy,
+            int[] truth_ids, int T, double radius, int[] ids, out long outliers);
+
+        // ---- device-resident forms (IntPtr = device address): for hosts that keep the cloud on the GPU between
+        // calls, and for the multi-GPU drivers (one process and one context per GPU) ----
+        [DllImport(Lib)] public static extern int vcp_dev_alloc(IntPtr ctx, ulong bytes, out IntPtr dptr);
+        [DllImport(Lib)] public static extern int vcp_dev_free(IntPtr ctx, IntPtr dptr);
+        [DllImport(Lib)] public static extern int vcp_h2d(IntPtr ctx, IntPtr dst_dev, double[] src_host, ulong bytes);
+        [DllImport(Lib)] public static extern int vcp_d2h(IntPtr ctx, int[] dst_host, IntPtr src_dev, ulong bytes);
+        [DllImport(Lib)] public static extern int vcp_dbscan_dev(IntPtr ctx, IntPtr d_coords, long n, int dim, int metric,
+            double eps, int min_pts, int cf_in, IntPtr d_in_classed, IntPtr d_labels, IntPtr d_is_core, IntPtr d_is_classed,
+            out int cf_out, out long dist_evals);
+        [DllImport(Lib)] public static extern int vcp_centroids_dev(IntPtr ctx, IntPtr d_xyz, IntPtr d_motor, IntPtr d_labels,
+            long n, int K, IntPtr d_c3, IntPtr d_c2, IntPtr d_counts);
+        [DllImport(Lib)] public static extern int vcp_icp_dev(IntPtr ctx, IntPtr d_model, long nm, IntPtr d_data, long nd,
+            double tol, int max_iter, int stop_rule, double[] R, double[] T, out double sse, out double rmse, out int iters);
+        // block pipeline in stages (per-block step sharded over GPUs, distributed.py: sharded_blocks)
+        [DllImport(Lib)] public static extern int vcp_blocks_begin(IntPtr ctx, double[] motor, long n, double eps, int min_pts,
+            int pts_in_cell, int small_max, out int rows, out int cols, out long nblocks, out long m);
+        [DllImport(Lib)] public static extern int vcp_blocks_begin_dev(IntPtr ctx, IntPtr d_motor, long n, double eps,
+            int min_pts, int pts_in_cell, int small_max, out int rows, out int cols, out long nblocks, out long m);
+        [DllImport(Lib)] public static extern int vcp_blocks_share(IntPtr ctx, int rank, int world, out int block_lo,
+            out int block_hi, out long pos_lo, out long pos_hi);
+        [DllImport(Lib)] public static extern int vcp_blocks_cluster_dev(IntPtr ctx, int block_lo, int block_hi, IntPtr d_local,
+            out long evals);
+        [DllImport(Lib)] public static extern int vcp_blocks_finish_dev(IntPtr ctx, IntPtr d_local, long evals_blocks,
+            IntPtr d_labels, IntPtr d_block_of, IntPtr d_merge_order, out long m_out, out int kept, out int del_sum,
+            out int cluster_amount, out long dist_evals);
+        // one DBImproved.dbscan spread over several GPUs (distributed.py: exact_slabs)
+        [DllImport(Lib)] public static extern int vcp_slab_begin(IntPtr ctx, IntPtr d_coords, long n, int dim, int metric,
+            double eps, int min_pts, IntPtr d_noexpand, IntPtr d_ord, IntPtr d_rep, IntPtr d_is_core, out long n_comp);
+        [DllImport(Lib)] public static extern int vcp_slab_comps(IntPtr ctx, uint[] comp_rep);
+        [DllImport(Lib)] public static extern int vcp_slab_finish(IntPtr ctx, uint[] map_rep, uint[] map_k, long n_tab,
+            int[] tab_gid, uint[] tab_seed, uint own_lo, uint own_count, IntPtr d_labels, IntPtr d_is_classed, out long twice);
+
         // one context per thread: StartCode runs on ThreadPool threads (FrmMain.cs:1358)
         [ThreadStatic] static IntPtr tlsCtx;
         public static IntPtr Ctx

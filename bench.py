@@ -272,6 +272,42 @@ def main():
             icp[tag] = {"rounds": r["iters"], "ms": best * 1e3, "rounds_per_s": r["iters"] / best,
                         "rmse": r["rmse"]}
         out["icp_1M_vs_100"] = icp
+        # the steps after the clustering on the same cloud: centroids of the 27 k clusters on the
+        # device, ICP of the centroids against a rotated + shifted copy ("truth"), matching
+        if metric_id == N.L1_2D:
+            K = int(cf)
+            d_xyz = torch.from_numpy(cloud["xyz"]).to(dev)
+            c3 = torch.zeros(K, 3, dtype=torch.float64, device=dev)
+            c2 = torch.zeros(K, 2, dtype=torch.float64, device=dev)
+            cnt = torch.zeros(K, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            t_c = None
+            for _ in range(3):
+                t1 = time.perf_counter()
+                ctx.centroids_dev(d_xyz.data_ptr(), d_coords.data_ptr(), d_labels.data_ptr(), n, K, c3.data_ptr(),
+                                  c2.data_ptr(), cnt.data_ptr())
+                e = time.perf_counter() - t1
+                t_c = e if t_c is None else min(t_c, e)
+            cen = c3.cpu().numpy()
+            Rt = synth.rotation_about((1.0, 1.0, 1.0), 0.2)
+            truth = cen @ Rt.T + np.array([0.3, -0.2, 0.1])
+            t_i = t_m = None
+            for _ in range(3):  # host-buffer entry points: best of three (the first call allocates)
+                t1 = time.perf_counter()
+                ri = ctx.icp(truth, cen, 1e-9, 100, N.STOP_SSE_DELTA)
+                e = time.perf_counter() - t1
+                t_i = e if t_i is None else min(t_i, e)
+                M = np.eye(4)
+                M[:3, :3] = ri["R"]
+                M[:3, 3] = ri["T"]
+                t1 = time.perf_counter()
+                mt = ctx.match(cen, truth, M, 0.5)
+                e = time.perf_counter() - t1
+                t_m = e if t_m is None else min(t_m, e)
+            out["after_clustering"] = {"clusters": K, "centroids_ms": t_c * 1e3, "icp_centroids_ms": t_i * 1e3,
+                                       "icp_rounds": ri["iters"], "icp_rmse": ri["rmse"], "match_ms": t_m * 1e3,
+                                       "matched": int(mt["count"])}
+            del d_xyz
         # the reference's production form: block-partitioned pipeline at its defaults (FrmMain.cs:1214-1544),
         # device-resident, staged API; only for the 2-D motor metric
         if metric_id == N.L1_2D:

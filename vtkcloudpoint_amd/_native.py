@@ -197,6 +197,11 @@ class Context:
                                       C.c_int32(K), _ptr(c3), _ptr(c2), _ptr(counts)))
         return c3, c2, counts
 
+    def centroids_dev(self, d_xyz, d_motor, d_labels, n, K, d_c3, d_c2, d_counts):
+        """Device-pointer form of centroids (any of d_xyz / d_motor and its output may be None)."""
+        self._chk(lib().vcp_centroids_dev(self._h, _ptr(d_xyz), _ptr(d_motor), _ptr(d_labels), C.c_int64(n),
+                                          C.c_int32(K), _ptr(d_c3), _ptr(d_c2), _ptr(d_counts)))
+
     def merge_centroids(self, cxy, ids, thr):
         cxy = _f64(cxy, 2)
         ids = np.ascontiguousarray(ids, np.int32)

@@ -25,9 +25,9 @@ namespace {
 constexpr int CT = 256;
 constexpr int CH = 16384;  // members per chunk
 
-__global__ __launch_bounds__(CT) void k_lab_hist(const int32_t* __restrict__ labels, int64_t n, int32_t K,
-                                                uint32_t* __restrict__ counts, uint32_t* __restrict__ keys,
-                                                uint32_t* __restrict__ vals, uint32_t* __restrict__ bad) {
+__global__ __launch_bounds__(CT) void k_lab_keys(const int32_t* __restrict__ labels, int64_t n, int32_t K,
+                                                uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                uint32_t* __restrict__ bad) {
   int64_t i = (int64_t)blockIdx.x * CT + threadIdx.x;
   if (i >= n) return;
   int32_t l = labels[i];
@@ -37,14 +37,26 @@ __global__ __launch_bounds__(CT) void k_lab_hist(const int32_t* __restrict__ lab
   }
   keys[i] = (uint32_t)l;
   vals[i] = (uint32_t)i;
-  if (l > 0) atomicAdd(&counts[l], 1u);  // counts[0] stays 0 for the noise bucket; slot l = cluster l
 }
 
-__global__ __launch_bounds__(CT) void k_nchunks(const uint32_t* __restrict__ counts, int32_t K,
-                                               uint32_t* __restrict__ nch) {
+// Segment bounds from the SORTED labels, no per-point atomics (global atomics run at the memory side here:
+// 5 M adds into 27 k counters cost more than the sort): mark[l] = (last slot of label l) + 1; the exclusive
+// max-scan of the marks is the first slot of every label; counts are the differences.
+__global__ __launch_bounds__(CT) void k_lab_mark(const uint32_t* __restrict__ skey, int64_t n, uint32_t* __restrict__ mark) {
+  int64_t t = (int64_t)blockIdx.x * CT + threadIdx.x;
+  if (t >= n) return;
+  const uint32_t k = skey[t];
+  if (t == n - 1 || skey[t + 1] != k) mark[k] = (uint32_t)t + 1u;
+}
+
+// counts[k] = members of cluster k (k = 0: the noise bucket, reported as 0 chunks), nch[k] = chunks of cluster k
+__global__ __launch_bounds__(CT) void k_nchunks(const uint32_t* __restrict__ segstart, int32_t K,
+                                               uint32_t* __restrict__ counts, uint32_t* __restrict__ nch) {
   int k = blockIdx.x * CT + threadIdx.x;
   if (k > K) return;
-  nch[k] = k == 0 ? 0u : (counts[k] + CH - 1) / CH;
+  const uint32_t c = segstart[k + 1] - segstart[k];
+  counts[k] = c;
+  nch[k] = k == 0 ? 0u : (c + CH - 1) / CH;
 }
 
 __device__ __forceinline__ double wsum(double v) {
@@ -137,8 +149,11 @@ int centroids_dev(vcp_ctx* ctx, const double* d_xyz, const double* d_motor, cons
   uint32_t* vals_in = ctx->b_aux2.as<uint32_t>();
   uint32_t* vals_out = vals_in + (n + 1);
   vcp_phase(ctx, "centroid_sort");
+  VCP_TRY(vcp_ensure(ctx, ctx->b_aux5, (size_t)(K + 4) * 4));
+  uint32_t* segstart = ctx->b_aux5.as<uint32_t>();  // [K+2]: first sorted slot of label k; [K+1] = n
   VCP_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)(K + 2) * 4 * 2 + 64, st));
-  hipLaunchKernelGGL(k_lab_hist, dim3(vcp_blocks(n, CT)), dim3(CT), 0, st, d_labels, n, K, counts, keys_in, vals_in, bad);
+  VCP_HIP(ctx, hipMemsetAsync(segstart, 0, (size_t)(K + 4) * 4, st));
+  hipLaunchKernelGGL(k_lab_keys, dim3(vcp_blocks(n, CT)), dim3(CT), 0, st, d_labels, n, K, keys_in, vals_in, bad);
   int bits = 1;
   while (((int64_t)1 << bits) <= K) bits++;
   size_t temp_bytes = 0;
@@ -147,9 +162,9 @@ int centroids_dev(vcp_ctx* ctx, const double* d_xyz, const double* d_motor, cons
   VCP_HIP(ctx, rocprim::radix_sort_pairs(ctx->b_aux3.p, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0,
                                          bits, st));
   vcp_phase(ctx, "centroid_reduce");
-  // segstart[k]: exclusive scan of member counts placed AFTER the noise bucket: slot 0 holds the noise count
-  // implicitly (n - sum), so scan counts shifted by the number of label-0 points.
-  hipLaunchKernelGGL(k_nchunks, dim3(vcp_blocks(K + 1, CT)), dim3(CT), 0, st, counts, K, nch);
+  if (n > 0) hipLaunchKernelGGL(k_lab_mark, dim3(vcp_blocks(n, CT)), dim3(CT), 0, st, keys_out, n, segstart);
+  VCP_TRY(vcp_exclusive_max_scan_u32(ctx, segstart, segstart, K + 2, nullptr));
+  hipLaunchKernelGGL(k_nchunks, dim3(vcp_blocks(K + 1, CT)), dim3(CT), 0, st, segstart, K, counts, nch);
   uint32_t* d_tot = bad + 4;
   VCP_TRY(vcp_exclusive_scan_u32(ctx, nch, nch, K + 2, d_tot));  // nch -> chunkstart, [K+1] = total chunks
   uint32_t* hp = reinterpret_cast<uint32_t*>(ctx->pinned);
@@ -157,23 +172,11 @@ int centroids_dev(vcp_ctx* ctx, const double* d_xyz, const double* d_motor, cons
   VCP_HIP(ctx, hipStreamSynchronize(st));
   if (hp[0] != 0) return vcp_fail(ctx, VCP_ERR_INDEX, "%u labels outside 0..K (clusList[clusterId-1], Tools.cs:185)", hp[0]);
   const uint32_t nchunks = hp[4];
-  // segstart: the sort puts label 0 first; members of cluster k start at zero_count + sum_{j<k} counts[j]
-  // -> reuse the scan on a copy of counts with counts[0] := number of label-0 points
-  VCP_TRY(vcp_ensure(ctx, ctx->b_aux5, (size_t)(K + 2) * 4));
-  uint32_t* segstart = ctx->b_aux5.as<uint32_t>();
-  VCP_HIP(ctx, hipMemcpyAsync(segstart, counts, (size_t)(K + 2) * 4, hipMemcpyDeviceToDevice, st));
-  // counts[0] is 0; the exclusive scan then gives offsets relative to the first member; add the noise
-  // count by scanning with an extra leading element: handled in-kernel through `zero` below.
-  VCP_TRY(vcp_exclusive_scan_u32(ctx, segstart, segstart, K + 2, d_tot + 1));
-  VCP_HIP(ctx, hipMemcpyAsync(hp, d_tot + 1, 4, hipMemcpyDeviceToHost, st));
-  VCP_HIP(ctx, hipStreamSynchronize(st));
-  const uint32_t members = hp[0];
-  const uint32_t zero = (uint32_t)n - members;  // label-0 points sort first
   VCP_TRY(vcp_ensure(ctx, ctx->b_aux4, ((size_t)nchunks + 1) * 5 * sizeof(double)));
   double* partial = ctx->b_aux4.as<double>();
   if (nchunks > 0)
-    hipLaunchKernelGGL(k_chunk_sums, dim3(nchunks), dim3(CT), 0, st, vals_out + zero, segstart, counts, nch, K, d_xyz,
-                       d_motor, partial);
+    hipLaunchKernelGGL(k_chunk_sums, dim3(nchunks), dim3(CT), 0, st, vals_out, segstart, counts, nch, K, d_xyz, d_motor,
+                       partial);
   hipLaunchKernelGGL(k_centroid_final, dim3(vcp_blocks(K, CT)), dim3(CT), 0, st, partial, counts, nch, K,
                      d_xyz != nullptr, d_motor != nullptr, d_c3, d_c2, d_counts);
   VCP_HIP(ctx, hipGetLastError());

@@ -66,11 +66,19 @@ __global__ __launch_bounds__(ITPB) void k_model32(const double* __restrict__ m, 
   o[j] = make_float4((float)a, (float)b, (float)c, (float)(0.5 * (a * a + b * b + c * c)));
 }
 
-__global__ __launch_bounds__(ITPB) void k_icp_pass(const double* __restrict__ model, const float4* __restrict__ model32,
-                                                  int nm, const double* __restrict__ data, int64_t nd,
-                                                  const IcpState* __restrict__ st, double* __restrict__ partial,
-                                                  int32_t* __restrict__ nn) {
+// TB = threads per workgroup (64 for small data sets, so that they spread over more CUs).  TILED: the screening
+// copy of the model is staged through LDS in tiles of MTILE points (every lane reads the same address: an LDS
+// broadcast).  The scalar-cache path is the faster one while the model fits that cache (C3: 100 points); a model
+// of thousands of points (ICP of cluster centroids against the truth list, MainForm.ICP's real use) makes every
+// scalar load an L2 round trip, 30x slower than the tiled form.
+constexpr int MTILE = 1024;
+template <int TB, bool TILED>
+__global__ __launch_bounds__(TB) void k_icp_pass(const double* __restrict__ model, const float4* __restrict__ model32,
+                                                int nm, const double* __restrict__ data, int64_t nd,
+                                                const IcpState* __restrict__ st, double* __restrict__ partial,
+                                                int32_t* __restrict__ nn) {
   if (st->done) return;
+  __shared__ float4 tile[TILED ? MTILE : 1];
   double R[9], T[3];
 #pragma unroll
   for (int k = 0; k < 9; k++) R[k] = st->R[k];
@@ -86,8 +94,11 @@ __global__ __launch_bounds__(ITPB) void k_icp_pass(const double* __restrict__ mo
   double s[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) s[k] = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * ITPB + threadIdx.x; i < nd; i += (int64_t)gridDim.x * ITPB) {
-    const double d0 = data[3 * i], d1 = data[3 * i + 1], d2 = data[3 * i + 2];
+  for (int64_t base = (int64_t)blockIdx.x * TB; base < nd; base += (int64_t)gridDim.x * TB) {  // uniform trip count
+    const int64_t i = base + threadIdx.x;
+    const bool live = i < nd;
+    const int64_t il = live ? i : nd - 1;  // idle lanes of the last workgroup recompute the last point, unused
+    const double d0 = data[3 * il], d1 = data[3 * il + 1], d2 = data[3 * il + 2];
     // TransPoint: r = R*p accumulated k ascending from 0 (Matrix.StupidMultiply), then + T
     double p[3];
 #pragma unroll
@@ -103,6 +114,37 @@ __global__ __launch_bounds__(ITPB) void k_icp_pass(const double* __restrict__ mo
     float b1 = INFINITY, b2 = INFINITY;
     int j1 = 0;
     int j = 0;
+    if (TILED) {
+      for (int t0 = 0; t0 < nm; t0 += MTILE) {
+        const int cnt = min(MTILE, nm - t0);
+        __syncthreads();  // the previous tile has been consumed
+        for (int k = threadIdx.x; k < cnt; k += TB) tile[k] = model32[t0 + k];
+        __syncthreads();
+        int u = 0;
+        for (; u + 3 < cnt; u += 4) {
+          float4 mm[4];
+#pragma unroll
+          for (int v = 0; v < 4; v++) mm[v] = tile[u + v];
+#pragma unroll
+          for (int v = 0; v < 4; v++) {
+            const float sc = __builtin_fmaf(-q0, mm[v].x, __builtin_fmaf(-q1, mm[v].y, __builtin_fmaf(-q2, mm[v].z, mm[v].w)));
+            const bool lt = sc < b1;
+            b2 = lt ? b1 : fminf(b2, sc);
+            j1 = lt ? t0 + u + v : j1;
+            b1 = lt ? sc : b1;
+          }
+        }
+        for (; u < cnt; u++) {
+          const float4 m4 = tile[u];
+          const float sc = __builtin_fmaf(-q0, m4.x, __builtin_fmaf(-q1, m4.y, __builtin_fmaf(-q2, m4.z, m4.w)));
+          const bool lt = sc < b1;
+          b2 = lt ? b1 : fminf(b2, sc);
+          j1 = lt ? t0 + u : j1;
+          b1 = lt ? sc : b1;
+        }
+      }
+      j = nm;
+    }
     for (; j + 3 < nm; j += 4) {
       float4 mm[4];
 #pragma unroll
@@ -125,7 +167,45 @@ __global__ __launch_bounds__(ITPB) void k_icp_pass(const double* __restrict__ mo
       b1 = lt ? sc : b1;
     }
     int order = j1;
-    if (!(b2 > b1 + tol2)) {
+    const bool amb = !(b2 > b1 + tol2);
+    if (TILED) {
+      // second sweep over the tiles for the lanes whose screening left more than one candidate; the whole
+      // workgroup walks the tiles (uniform barriers), only ambiguous lanes look at them
+      if (__syncthreads_or(amb ? 1 : 0)) {
+        const float lim = b1 + tol2;
+        const bool all = !(lim == lim);  // non-finite bound: every model point is a candidate
+        double best = INFINITY;
+        bool have = false;
+        if (amb) order = 0;
+        for (int t0 = 0; t0 < nm; t0 += MTILE) {
+          const int cnt = min(MTILE, nm - t0);
+          __syncthreads();
+          for (int k = threadIdx.x; k < cnt; k += TB) tile[k] = model32[t0 + k];
+          __syncthreads();
+          if (!amb) continue;
+          for (int u = 0; u < cnt; u += 4) {
+            float sc[4];
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+              const float4 m4 = tile[min(u + v, cnt - 1)];
+              sc[v] = __builtin_fmaf(-q0, m4.x, __builtin_fmaf(-q1, m4.y, __builtin_fmaf(-q2, m4.z, m4.w)));
+            }
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+              if (u + v >= cnt || !(sc[v] <= lim || !(sc[v] == sc[v]) || all)) continue;
+              const int jj = t0 + u + v;
+              const double e0 = p[0] - model[3 * jj], e1 = p[1] - model[3 * jj + 1], e2 = p[2] - model[3 * jj + 2];
+              const double dd = e0 * e0 + e1 * e1 + e2 * e2;
+              if (!have || dd < best) {
+                best = dd;
+                order = jj;
+                have = true;
+              }
+            }
+          }
+        }
+      }
+    } else if (amb) {
       // more than one candidate within the bound (or non-finite values): exact binary64 among the candidates, in
       // index order, strict `<` -- FindClosestPointSet's rule (the C# seeds with model[0] and replaces on `<`, so
       // the lowest index among the exact minima wins; every exact minimum is a candidate by the bound)
@@ -147,6 +227,7 @@ __global__ __launch_bounds__(ITPB) void k_icp_pass(const double* __restrict__ mo
         }
       }
     }
+    if (!live) continue;
     if (nn) nn[i] = order;
     const double y0 = model[3 * order], y1 = model[3 * order + 1], y2 = model[3 * order + 2];
     const double y[3] = {y0, y1, y2};
@@ -160,7 +241,7 @@ __global__ __launch_bounds__(ITPB) void k_icp_pass(const double* __restrict__ mo
     const double e0 = p[0] - y0, e1 = p[1] - y1, e2 = p[2] - y2;
     s[15] += e0 * e0 + e1 * e1 + e2 * e2;
   }
-  __shared__ double sm[ITPB / 64][16];
+  __shared__ double sm[TB / 64][16];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < 16; k++) {
@@ -171,7 +252,7 @@ __global__ __launch_bounds__(ITPB) void k_icp_pass(const double* __restrict__ mo
   if (threadIdx.x < 16) {
     double v = sm[0][threadIdx.x];
 #pragma unroll
-    for (int k = 1; k < ITPB / 64; k++) v += sm[k][threadIdx.x];
+    for (int k = 1; k < TB / 64; k++) v += sm[k][threadIdx.x];
     partial[(size_t)blockIdx.x * 16 + threadIdx.x] = v;
   }
 }
@@ -366,7 +447,11 @@ void identity(IcpState& s) {
 int icp_run(vcp_ctx* ctx, const double* d_model, int64_t nm, const double* d_data, int64_t nd, const IcpState& init,
             double tol, int stop_rule, int max_iter, int mode, IcpState* out, int32_t* d_nn) {
   hipStream_t st = ctx->stream;
-  const int nb = (int)vcp_blocks(nd, ITPB, ICP_MAX_BLOCKS);
+  // small data sets: one wave per workgroup so that they reach more CUs; large models: LDS tiles
+  const bool small = nd <= (int64_t)64 * ICP_MAX_BLOCKS;
+  const bool tiled = nm > 512;
+  const int tb = small ? 64 : ITPB;
+  const int nb = (int)vcp_blocks(nd, tb, ICP_MAX_BLOCKS);
   VCP_TRY(vcp_ensure(ctx, ctx->b_icp_part, (size_t)ICP_MAX_BLOCKS * 16 * sizeof(double) + sizeof(IcpState) + 256));
   VCP_TRY(vcp_ensure(ctx, ctx->b_aux0, (size_t)nm * sizeof(float4) + 64));
   double* part = ctx->b_icp_part.as<double>();
@@ -382,7 +467,13 @@ int icp_run(vcp_ctx* ctx, const double* d_model, int64_t nm, const double* d_dat
   for (;;) {
     const int batch = mode == MODE_SUMS_ONLY ? 1 : std::min(ICP_BATCH, max_iter - launched);
     for (int b = 0; b < batch; b++) {
-      hipLaunchKernelGGL(k_icp_pass, dim3(nb), dim3(ITPB), 0, st, d_model, model32, (int)nm, d_data, nd, d_st, part, d_nn);
+#define VCP_PASS(TBV, TL) \
+  hipLaunchKernelGGL((k_icp_pass<TBV, TL>), dim3(nb), dim3(TBV), 0, st, d_model, model32, (int)nm, d_data, nd, d_st, part, d_nn)
+      if (small && tiled) VCP_PASS(64, true);
+      else if (small) VCP_PASS(64, false);
+      else if (tiled) VCP_PASS(ITPB, true);
+      else VCP_PASS(ITPB, false);
+#undef VCP_PASS
       hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(ITPB), 0, st, part, nb, d_st, (long long)nd, tol, stop_rule, max_iter,
                          mode);
     }

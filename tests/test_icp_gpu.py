@@ -82,3 +82,23 @@ def test_vtklike_icp_configuration(vcp_ctx, oracle):
         nn = oracle.find_closest(truth, moved)
         assert np.abs(moved - truth[nn]).max() < 1e-6 and g["mean_dist"] < 1e-6
         assert abs(g["M"][2, 2] - 1) < 1e-9 and np.abs(g["M"][2, :2]).max() < 1e-9  # planar input: rotation about z
+
+
+@pytest.mark.parametrize("nd", [3000, 70000])
+def test_large_model_goes_through_lds_tiles(vcp_ctx, oracle, nd):
+    """Model beyond the scalar-cache path (nm > 512): LDS tiles, and one-wave workgroups for the small data set.
+    Coordinates on a coarse lattice produce many exact distance ties (lowest model index must win) and a large
+    absolute offset makes the binary32 screening ambiguous for most points (second sweep)."""
+    rng = np.random.default_rng(nd)
+    model = rng.integers(0, 24, size=(2500, 3)).astype(np.float64) * 0.5 + 1000.0   # duplicates included
+    data = rng.integers(0, 48, size=(nd, 3)).astype(np.float64) * 0.25 + 1000.0
+    sums, nn = vcp_ctx.icp_sums(model, data)
+    assert np.array_equal(nn, oracle.find_closest(model, data))
+    assert np.allclose(sums, oracle.icp_sums(model, data), rtol=1e-12, atol=1e-6)
+    # K x K form of MainForm.ICP: centroids against a rotated + shifted copy
+    cen = np.round(rng.uniform(0, 200.0, (2000, 3)) * 1024) / 1024
+    truth = cen @ synth.rotation_about((1.0, 1.0, 1.0), 0.2).T + np.array([0.3, -0.2, 0.1])
+    g = vcp_ctx.icp(truth, cen, 1e-9, 100, N.STOP_SSE_DELTA)
+    o = oracle.icp(truth, cen, 1e-9, 100, N.STOP_SSE_DELTA)
+    assert g["iters"] == o["iters"]
+    assert np.abs(g["R"] - o["R"]).max() < TOL and np.abs(g["T"] - o["T"]).max() < TOL and g["rmse"] < 1e-9

@@ -1298,7 +1298,7 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   if (!(cellw > 0.0)) cellw = 1.0;
   int64_t budget = n * 32;
   if (budget < (1 << 16)) budget = 1 << 16;
-  if (budget > ((int64_t)1 << 28)) budget = (int64_t)1 << 28;
+  if (budget > ((int64_t)1 << 31) - 16) budget = ((int64_t)1 << 31) - 16;  // cell ids and ncells + 1 stay in 31 bits
   int64_t ncells = 0;
   for (int it = 0; it < 400; it++) {
     ncells = 1;

@@ -420,6 +420,7 @@ template <int GD, int METRIC, bool GROUPED>
 __global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted, GridP g, double thr, int min_pts,
                                              const uint32_t* __restrict__ cellstart,
                                              const int32_t* __restrict__ sgroup, uint8_t* __restrict__ flags,
+                                             uint32_t* __restrict__ parent, uint32_t* __restrict__ minord,
                                              uint32_t* __restrict__ blkE, uint32_t* __restrict__ blkB) {
   const uint32_t nin = cellstart[g.ncells];
   const int64_t blk = xcd_block(gridDim.x);
@@ -471,7 +472,13 @@ __global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted,
     isB = cnt > 1;  // no early exit happened, so cnt is exact: 1 = nobody but itself within eps
   }
   if (isB) fl |= F_BCAND;
-  if (live) flags[p] = fl;
+  if (live) {
+    flags[p] = fl;
+    // union-find start: parent[p] = p for expanding points, NONE for all others, so that the component kernels
+    // can tell "expanding, and in which tree" from ONE 4-byte load per candidate
+    parent[p] = isE ? (uint32_t)p : NONE;
+    minord[p] = NONE;
+  }
   wl_count(isE, isB, (uint32_t)blk, blkE, blkB);
 }
 
@@ -541,6 +548,7 @@ __device__ __forceinline__ void tile_load(RowTile& t, const double* __restrict__
 template <int METRIC>
 __global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sorted, GridP g, double thr, int min_pts,
                                                  const uint32_t* __restrict__ cellstart, uint8_t* __restrict__ flags,
+                                                 uint32_t* __restrict__ parent, uint32_t* __restrict__ minord,
                                                  uint32_t* __restrict__ blkE, uint32_t* __restrict__ blkB) {
   __shared__ RowTile t;
   const uint32_t nin = cellstart[g.ncells];
@@ -605,7 +613,13 @@ __global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sor
     isB = cnt > 1;
   }
   if (isB) fl |= F_BCAND;
-  if (live) flags[p] = fl;
+  if (live) {
+    flags[p] = fl;
+    // union-find start: parent[p] = p for expanding points, NONE for all others, so that the component kernels
+    // can tell "expanding, and in which tree" from ONE 4-byte load per candidate
+    parent[p] = isE ? (uint32_t)p : NONE;
+    minord[p] = NONE;
+  }
   wl_count(isE, isB, (uint32_t)blk, blkE, blkB);
 }
 
@@ -649,18 +663,6 @@ __device__ __forceinline__ uint32_t uf_link(uint32_t* parent, uint32_t ra, uint3
     rb = uf_root(parent, rb);
   }
   return ra;
-}
-
-// parent[p] = p for expanding points, NONE for all others: the component kernels can then tell "expanding and
-// in which tree" from ONE 4-byte load per candidate
-__global__ __launch_bounds__(TPB) void k_init_parent(uint32_t* __restrict__ parent, uint32_t* __restrict__ minord,
-                                                    const uint8_t* __restrict__ flags,
-                                                    const uint32_t* __restrict__ cellstart, uint32_t ncells) {
-  const uint32_t nin = cellstart[ncells];
-  int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
-  if (p >= nin) return;
-  parent[p] = (flags[p] & F_EXPAND) ? (uint32_t)p : NONE;
-  minord[p] = NONE;
 }
 
 // Phase 1 of the component build: every expanding point links to the first expanding neighbour within eps
@@ -1392,18 +1394,17 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   VCP_HIP(ctx, hipMemsetAsync(blkE, 0, (size_t)(nb + 2) * 2 * 4, st));
   const unsigned nbl = 8u * LCHUNK * wlE.perblk;  // list kernels: see wl_fetch
   if constexpr (GD == 2 && !GROUPED)
-    hipLaunchKernelGGL((k_core_lds<METRIC>), dim3(nb), dim3(TPB), 0, st, sorted, g, thr, min_pts, cellcnt, flags, blkE,
-                       blkB);
+    hipLaunchKernelGGL((k_core_lds<METRIC>), dim3(nb), dim3(TPB), 0, st, sorted, g, thr, min_pts, cellcnt, flags, parent,
+                       minord, blkE, blkB);
   else
     hipLaunchKernelGGL((k_core<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 0, st, sorted, g, thr, min_pts, cellcnt, sgroup,
-                       flags, blkE, blkB);
+                       flags, parent, minord, blkE, blkB);
   VCP_TRY(vcp_exclusive_scan_u32(ctx, blkE, blkE, (int64_t)nb + 1, nullptr));
   VCP_TRY(vcp_exclusive_scan_u32(ctx, blkB, blkB, (int64_t)nb + 1, nullptr));
   hipLaunchKernelGGL(k_wl_fill, dim3(nb), dim3(TPB), 0, st, flags, cellcnt, g.ncells, blkE, blkB, wlE.list, wlB.list);
 
   // 6. components of the expanding points
   vcp_phase(ctx, "union");
-  hipLaunchKernelGGL(k_init_parent, dim3(nb), dim3(TPB), 0, st, parent, minord, flags, cellcnt, g.ncells);
   VCP_HIP(ctx, hipMemsetAsync(seedflag, 0, (size_t)nw * 4, st));
   VCP_HIP(ctx, hipMemsetAsync(counters, 0, 36 * sizeof(unsigned long long), st));
   // phases 1-2 pay for their extra search pass in 2-D (3 rows); in 3-D (9 rows) they do not (measured: +28 %)

@@ -65,3 +65,34 @@ def test_synth_is_deterministic_and_quantised():
     assert synth.splitmix64(1, 2, 3).tolist() == synth.splitmix64(1, 0, 5)[2:].tolist()  # counter-based
     c = synth.config_icp(nd=1000, nm=20, jitter=0.0)
     assert np.allclose(c["data"] @ c["R_true"].T + c["T_true"], c["model"][np.arange(1000) % 20], atol=1e-12)
+
+
+def test_text_formats_round_trip(tmp_path):
+    """Scan files (motor_x TAB motor_y TAB Distance, FrmMain.cs:1005-1009 / Tools.cs:233) and the clustering
+    export (clusterId TAB ..., Tools.cs:366-392)."""
+    import pytest
+    from vtkcloudpoint_amd import io as vio
+    from vtkcloudpoint_amd.datamodel import ClusObj, Point3D
+    pts = []
+    for k, (a, b, d) in enumerate([(1.5, -2.25, 10.0), (0.125, 3.0, 999.5), (-7.0, 0.0, 0.0)]):
+        p = Point3D()
+        p.motor_x, p.motor_y, p.Distance, p.clusterId = a, b, d, k % 2 + 1
+        pts.append(p)
+    f = tmp_path / "scan.txt"
+    vio.write_scan_text(str(f), pts, bit=4)
+    raw = open(f, "rb").read()
+    assert raw.startswith(b"1.5000\t-2.2500\t10.0000\r\n")
+    rows = vio.read_scan_text(str(f))
+    assert rows.tolist() == [[1.5, -2.25, 10.0], [0.125, 3.0, 999.5], [-7.0, 0.0, 0.0]]
+    c1, c2 = ClusObj(), ClusObj()
+    c1.li, c2.li = [pts[0], pts[2]], [pts[1]]
+    g = tmp_path / "clusters.txt"
+    vio.write_clusters_text(str(g), [c1, c2], bit=2)
+    assert open(g).read().split("\n")[:3] == ["1\t1.50\t-2.25\t10.00", "1\t-7.00\t0.00\t0.00", "2\t0.12\t3.00\t999.50"]
+    bad = tmp_path / "bad.txt"
+    bad.write_text("1.0\t2.0\n")
+    with pytest.raises(ValueError):
+        vio.read_scan_text(str(bad))
+    bad.write_text("1.0\tx\t3.0\n")
+    with pytest.raises(ValueError):
+        vio.read_scan_text(str(bad))

@@ -110,3 +110,49 @@ def test_cpp_host_mirror_demo():
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "PASS host_demo" in out.stdout, out.stdout + out.stderr
+
+
+def test_scan_files_to_cluster_export(vcp_ctx, oracle, tmp_path):
+    """File -> import (filter, spherical conversion, duplicate removal over all files) -> DBImproved -> export, in
+    the reference's text formats; the import is checked against the oracle's literal AddFolder restatement."""
+    from vtkcloudpoint_amd import io as vio
+    from vtkcloudpoint_amd.datamodel import ClusObj
+    from vtkcloudpoint_amd.dbscan import DBImproved
+    rng = np.random.default_rng(12)
+    files, allrows = [], []
+    for k in range(3):
+        n = 4000
+        rows = np.empty((n, 3))
+        c = rng.uniform(-20, 20, (8, 2))
+        rows[:, :2] = np.round((c[rng.integers(0, 8, n)] + rng.normal(0, 0.4, (n, 2))) * 64) / 64
+        rows[:, 2] = np.round(rng.uniform(5, 40, n) * 16) / 16
+        rows[::97, 2] = 0.0          # filtered: Distance == 0
+        rows[5::113, 2] = 1500.0     # filtered: Distance > 1000
+        rows[10:60] = rows[200:250]  # exact duplicates inside a file
+        if k:
+            rows[300:330] = allrows[0][400:430]  # and across files
+        f = tmp_path / ("scan%d.txt" % k)
+        with open(f, "w", newline="\r\n") as fh:
+            for r in rows:
+                fh.write("%r\t%r\t%r\n" % (float(r[0]), float(r[1]), float(r[2])))
+        files.append(str(f))
+        allrows.append(rows)
+    raw, dup, paths = vio.add_folder(files, x_angle=1.0, y_angle=-0.5, typpe=1, ctx=vcp_ctx)
+    ref = oracle.import_convert(np.concatenate(allrows), 1.0, -0.5, 2, 1, True, literal=True)
+    assert dup == ref["duplicates"] and len(raw) == ref["kept"] and dup > 100
+    keep = np.nonzero(ref["state"] == 1)[0]
+    got = np.array([(p.X, p.Y, p.Z) for p in raw])
+    assert np.allclose(got, ref["xyz"][keep], rtol=1e-12, atol=1e-12)
+    assert [p.pathId for p in raw] == (keep // 4000).tolist() and paths == files
+    db = DBImproved(vcp_ctx)
+    db.dbscan(raw, 0.5, 8)
+    o = oracle.dbscan(np.array([(p.motor_x, p.motor_y) for p in raw]), 0.5, 8)
+    assert [p.clusterId for p in raw] == o["labels"].tolist() and db.clusterAmount == o["cf"] > 3
+    clus = [ClusObj() for _ in range(db.clusterAmount)]
+    for p in raw:
+        if p.clusterId:
+            clus[p.clusterId - 1].li.append(p)
+    out = tmp_path / "clusters.txt"
+    vio.write_clusters_text(str(out), clus, bit=3)
+    lines = open(out).read().split("\n")
+    assert len(lines) - 1 == int((o["labels"] > 0).sum()) and lines[0].startswith("1\t")

@@ -130,6 +130,33 @@ def test_truth_guided_assignment(vcp_ctx, oracle):
     assert out == 10 and not ids.any()
 
 
+def test_truth_grid_equals_brute_force(vcp_ctx, oracle):
+    """The grid over the truths (radius-sized cells) against the oracle's literal LINQ query: lattice coordinates
+    give many exactly equal distances (the LAST truth in list order must win), duplicate truths, truths with NaN /
+    inf coordinates, raw points far outside the truths' bounding box, and radii for which the grid does not apply
+    (0, negative, inf, NaN -> brute-force kernel)."""
+    rng = np.random.default_rng(77)
+    n, T = 60_000, 900
+    motor = rng.integers(-40, 240, size=(n, 2)).astype(np.float64) * 0.25
+    motor[::501] = np.nan
+    txy = rng.integers(0, 160, size=(T, 2)).astype(np.float64) * 0.25
+    txy[100:130] = txy[0:30]                      # duplicates: the later one wins
+    txy[5] = (np.nan, 1.0)
+    txy[6] = (np.inf, 2.0)
+    tids = rng.integers(0, 50, size=T).astype(np.int32)
+    for radius in (0.75, 1.0, 2.5, 13.0, 1e6, 0.0, -1.0, float("inf"), float("nan")):
+        o_ids, o_out = oracle.assign_truths(motor, txy, tids, radius)
+        g_ids, g_out = vcp_ctx.assign_truths(motor, txy, tids, radius)
+        assert np.array_equal(o_ids, g_ids) and o_out == g_out, radius
+    # a single truth, and truths on one vertical line (zero extent in x)
+    line = np.c_[np.full(40, 3.0), np.arange(40) * 0.5]
+    for t in (txy[:1], line):
+        ti = np.arange(1, len(t) + 1, dtype=np.int32)
+        o_ids, o_out = oracle.assign_truths(motor, t, ti, 1.25)
+        g_ids, g_out = vcp_ctx.assign_truths(motor, t, ti, 1.25)
+        assert np.array_equal(o_ids, g_ids) and o_out == g_out
+
+
 def test_import_conversion_and_duplicate_removal(vcp_ctx, oracle):
     """MainForm.AddFolder: Distance filter, spherical -> Cartesian, first-occurrence dedupe."""
     rng = np.random.default_rng(12)

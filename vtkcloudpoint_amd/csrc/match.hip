@@ -4,6 +4,10 @@
 // FrmMain.cs:3588-3618 with getDisP :829-835: nearest truth point by sqrt(dx^2+dy^2+dz^2) (binary64,
 // correctly rounded sqrt), strict `<` so the lowest index wins ties, matched iff distance < max_dist.
 // One thread per centroid; the truth index is wave-uniform, so truths are read through the scalar cache.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
 #include "vcp_ctx.hpp"
 
 namespace {
@@ -85,6 +89,116 @@ __global__ __launch_bounds__(256) void k_assign_truths(const double* __restrict_
     if (t) atomicAdd(&outliers[blockIdx.x & 31], (unsigned long long)t);
   }
 }
+// The same query through a grid over the TRUTHS (cell edge >= radius): a raw point only meets the truths of its
+// 3 x 3 cells, so the cost is O(n) instead of O(n T).  Candidates are evaluated with the identical binary64
+// expression; "last truth in list order among equal distances" is carried by the original truth index.
+struct TruthGrid {
+  double x0, y0, inv_h;
+  int Dx, Dy;
+};
+__global__ __launch_bounds__(256) void k_assign_truths_grid(const double* __restrict__ motor, int64_t n, TruthGrid g,
+                                                           const uint32_t* __restrict__ cellstart,
+                                                           const double* __restrict__ txy, const int32_t* __restrict__ tid,
+                                                           const int32_t* __restrict__ torig, double radius,
+                                                           int32_t* __restrict__ ids,
+                                                           unsigned long long* __restrict__ outliers) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  bool none = false;
+  if (i < n) {
+    const double2 p = *reinterpret_cast<const double2*>(motor + 2 * i);
+    int32_t id = 0, borig = -1;
+    double best = 0;
+    const double ux = (p.x - g.x0) * g.inv_h, uy = (p.y - g.y0) * g.inv_h;
+    // a point more than one cell outside the truths' bounding box (or NaN) has no truth within the radius
+    if (ux >= -1.0 && ux < (double)g.Dx + 1.0 && uy >= -1.0 && uy < (double)g.Dy + 1.0) {
+      const int cx = (int)floor(ux), cy = (int)floor(uy);
+      const int xa = max(cx - 1, 0), xb = min(cx + 1, g.Dx - 1);
+      for (int y = max(cy - 1, 0); y <= min(cy + 1, g.Dy - 1); y++) {
+        if (xa > xb) break;
+        const uint32_t s0 = cellstart[(size_t)y * g.Dx + xa], s1 = cellstart[(size_t)y * g.Dx + xb + 1];
+        for (uint32_t s = s0; s < s1; s++) {
+          const double ax = txy[2 * s] - p.x, ay = txy[2 * s + 1] - p.y;
+          const double d = sqrt(ax * ax + ay * ay);
+          if (d < radius && (borig < 0 || d < best || (d == best && torig[s] > borig))) {
+            best = d;
+            id = tid[s];
+            borig = torig[s];
+          }
+        }
+      }
+    }
+    ids[i] = id;
+    none = id == 0;
+  }
+  __shared__ unsigned wc[4];
+  unsigned long long b = __ballot(none);
+  if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = (unsigned)__popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned t = wc[0] + wc[1] + wc[2] + wc[3];
+    if (t) atomicAdd(&outliers[blockIdx.x & 31], (unsigned long long)t);
+  }
+}
+
+// host side of the grid: counting sort of the finite truths by cell.  Returns false when the grid form does not
+// apply (radius not a positive finite number, no finite truth, or degenerate extents) -> brute force.
+bool build_truth_grid(const double* txy, const int32_t* tid, int32_t T, double radius, TruthGrid* g,
+                      std::vector<uint32_t>* cellstart, std::vector<double>* sxy, std::vector<int32_t>* sid,
+                      std::vector<int32_t>* sorig) {
+  if (!(radius > 0.0) || !std::isfinite(radius) || T <= 0) return false;
+  double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+  int32_t nf = 0;
+  for (int32_t s = 0; s < T; s++) {
+    const double x = txy[2 * s], y = txy[2 * s + 1];
+    if (!std::isfinite(x) || !std::isfinite(y)) continue;  // never within a finite radius
+    x0 = std::min(x0, x);
+    x1 = std::max(x1, x);
+    y0 = std::min(y0, y);
+    y1 = std::max(y1, y);
+    nf++;
+  }
+  if (nf == 0) return false;
+  double h = radius * (1.0 + 1.0 / 1048576.0);
+  for (int it = 0; it < 200; it++) {
+    const double dx = (x1 - x0) / h, dy = (y1 - y0) / h;
+    if (std::isfinite(dx) && std::isfinite(dy) && (dx + 1.0) * (dy + 1.0) <= 4194304.0) break;
+    h *= 2.0;
+  }
+  const double dx = (x1 - x0) / h, dy = (y1 - y0) / h;
+  if (!std::isfinite(h) || !std::isfinite(dx) || !std::isfinite(dy) || (dx + 1.0) * (dy + 1.0) > 4194304.0) return false;
+  g->x0 = x0;
+  g->y0 = y0;
+  g->inv_h = 1.0 / h;
+  g->Dx = (int)dx + 1;
+  g->Dy = (int)dy + 1;
+  const size_t nc = (size_t)g->Dx * g->Dy;
+  cellstart->assign(nc + 1, 0u);
+  std::vector<uint32_t> cell((size_t)T, 0xFFFFFFFFu);
+  for (int32_t s = 0; s < T; s++) {
+    const double x = txy[2 * s], y = txy[2 * s + 1];
+    if (!std::isfinite(x) || !std::isfinite(y)) continue;
+    int cx = (int)std::floor((x - x0) * g->inv_h), cy = (int)std::floor((y - y0) * g->inv_h);
+    cx = std::min(std::max(cx, 0), g->Dx - 1);
+    cy = std::min(std::max(cy, 0), g->Dy - 1);
+    cell[s] = (uint32_t)((size_t)cy * g->Dx + cx);
+    (*cellstart)[cell[s] + 1]++;
+  }
+  for (size_t c = 0; c < nc; c++) (*cellstart)[c + 1] += (*cellstart)[c];
+  sxy->assign((size_t)nf * 2, 0.0);
+  sid->assign((size_t)nf, 0);
+  sorig->assign((size_t)nf, 0);
+  std::vector<uint32_t> cur(cellstart->begin(), cellstart->end() - 1);
+  for (int32_t s = 0; s < T; s++) {
+    if (cell[s] == 0xFFFFFFFFu) continue;
+    const uint32_t k = cur[cell[s]]++;
+    (*sxy)[2 * (size_t)k] = txy[2 * s];
+    (*sxy)[2 * (size_t)k + 1] = txy[2 * s + 1];
+    (*sid)[k] = tid[s];
+    (*sorig)[k] = s;
+  }
+  return true;
+}
+
 }  // namespace
 
 extern "C" int vcp_assign_truths(vcp_ctx* ctx, const double* motor, int64_t n, const double* truths_xy,
@@ -108,9 +222,26 @@ extern "C" int vcp_assign_truths(vcp_ctx* ctx, const double* motor, int64_t n, c
     VCP_HIP(ctx, hipMemcpyAsync(ctx->b_in3.p, truth_ids, (size_t)T * 4, hipMemcpyHostToDevice, st));
   }
   VCP_HIP(ctx, hipMemsetAsync(ctx->b_out2.p, 0, 32 * 8, st));
-  hipLaunchKernelGGL(k_assign_truths, dim3(vcp_blocks(n, 256)), dim3(256), 0, st, ctx->b_in0.as<double>(), n,
-                     ctx->b_in2.as<double>(), ctx->b_in3.as<int32_t>(), T, radius, ctx->b_out0.as<int32_t>(),
-                     ctx->b_out2.as<unsigned long long>());
+  TruthGrid tg;
+  std::vector<uint32_t> h_cellstart;
+  std::vector<double> h_sxy;
+  std::vector<int32_t> h_sid, h_sorig;
+  if (build_truth_grid(truths_xy, truth_ids, T, radius, &tg, &h_cellstart, &h_sxy, &h_sid, &h_sorig)) {
+    VCP_TRY(vcp_ensure(ctx, ctx->b_aux0, h_cellstart.size() * 4));
+    VCP_TRY(vcp_ensure(ctx, ctx->b_aux1, h_sid.size() * 4 + 16));
+    VCP_HIP(ctx, hipMemcpyAsync(ctx->b_aux0.p, h_cellstart.data(), h_cellstart.size() * 4, hipMemcpyHostToDevice, st));
+    VCP_HIP(ctx, hipMemcpyAsync(ctx->b_in2.p, h_sxy.data(), h_sxy.size() * 8, hipMemcpyHostToDevice, st));
+    VCP_HIP(ctx, hipMemcpyAsync(ctx->b_in3.p, h_sid.data(), h_sid.size() * 4, hipMemcpyHostToDevice, st));
+    VCP_HIP(ctx, hipMemcpyAsync(ctx->b_aux1.p, h_sorig.data(), h_sorig.size() * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_assign_truths_grid, dim3(vcp_blocks(n, 256)), dim3(256), 0, st, ctx->b_in0.as<double>(), n, tg,
+                       ctx->b_aux0.as<uint32_t>(), ctx->b_in2.as<double>(), ctx->b_in3.as<int32_t>(),
+                       ctx->b_aux1.as<int32_t>(), radius, ctx->b_out0.as<int32_t>(), ctx->b_out2.as<unsigned long long>());
+    VCP_HIP(ctx, hipStreamSynchronize(st));  // the host vectors above are the source of the async copies
+  } else {
+    hipLaunchKernelGGL(k_assign_truths, dim3(vcp_blocks(n, 256)), dim3(256), 0, st, ctx->b_in0.as<double>(), n,
+                       ctx->b_in2.as<double>(), ctx->b_in3.as<int32_t>(), T, radius, ctx->b_out0.as<int32_t>(),
+                       ctx->b_out2.as<unsigned long long>());
+  }
   VCP_HIP(ctx, hipGetLastError());
   unsigned long long* hp = reinterpret_cast<unsigned long long*>(ctx->pinned);
   VCP_HIP(ctx, hipMemcpyAsync(ids, ctx->b_out0.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));

@@ -68,19 +68,50 @@ def main():
              "coalesced reads (uncalibrated for narrow/gather accesses, so both are shown).", "",
              "| kernel | calls | avg us | % | FETCH_SIZE B | fetch x2 B | WRITE_SIZE B |", "|---|---|---|---|---|---|---|"]
     per_phase = defaultdict(lambda: {"fetch_raw": 0.0, "write": 0.0, "avg_us": 0.0})
+    # template instantiations of one kernel are one line: calls and time summed, average = total / calls
+    agg, order = {}, []
     for r in rows:
         k = short(r["Name"])
+        if k not in agg:
+            agg[k] = [0, 0.0, 0.0]
+            order.append(k)
+        agg[k][0] += int(r["Calls"])
+        agg[k][1] += float(r["TotalDurationNs"])
+        agg[k][2] += float(r["Percentage"])
+    steps = max(agg.get("k_output", [1])[0], 1)  # launches of the per-step kernels = profiled steps
+    for k in order:
+        calls, tot, pct = agg[k]
         fz = pmc["FETCH_SIZE"].get(k)
         wz = pmc["WRITE_SIZE"].get(k)
-        lines.append("| %s | %s | %.1f | %s | %s | %s | %s |" % (
-            k, r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"],
+        lines.append("| %s | %d | %.1f | %.2f | %s | %s | %s |" % (
+            k, calls, tot / calls / 1e3, pct,
             "%.3e" % fz if fz is not None else "-", "%.3e" % (2 * fz) if fz is not None else "-",
             "%.3e" % wz if wz is not None else "-"))
         ph = PHASE_OF.get(k)
         if ph and fz is not None and wz is not None:
-            per_phase[ph]["fetch_raw"] += fz
-            per_phase[ph]["write"] += wz
-            per_phase[ph]["avg_us"] += float(r["AverageNs"]) / 1e3
+            per_step = calls / steps  # a kernel launched several times per step (the scans) counts that often
+            per_phase[ph]["fetch_raw"] += fz * per_step
+            per_phase[ph]["write"] += wz * per_step
+            per_phase[ph]["avg_us"] += tot / steps / 1e3
+    extras = newest(os.path.join(src, "stats_extras", "*", "*_kernel_stats.csv"))
+    if extras:
+        with open(extras[0]) as fh:
+            erows = list(csv.DictReader(fh))
+        lines += ["", "Kernels of the side measurements (`bench.py` with its extras: ICP 1 M x 100, centroids / ICP / matching "
+                  "after the clustering, block pipeline), kernel time only:", "",
+                  "| kernel | calls | avg us | total ms |", "|---|---|---|---|"]
+        eagg, eorder = {}, []
+        for r in erows:
+            k = short(r["Name"])
+            if k in agg and not k.startswith("k_icp"):
+                continue  # already in the table above
+            if k not in eagg:
+                eagg[k] = [0, 0.0]
+                eorder.append(k)
+            eagg[k][0] += int(r["Calls"])
+            eagg[k][1] += float(r["TotalDurationNs"])
+        for k in eorder[:30]:
+            lines.append("| %s | %d | %.1f | %.2f |" % (k, eagg[k][0], eagg[k][1] / eagg[k][0] / 1e3, eagg[k][1] / 1e6))
     with open(os.path.join(out_dir, "%s_%s_rocprof.md" % (tag, metric)), "w") as f:
         f.write("\n".join(lines) + "\n")
     latest = os.path.join(out_dir, "pmc_latest.json")

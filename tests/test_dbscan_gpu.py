@@ -123,3 +123,25 @@ def test_dense_cells_exceed_the_lds_tile(vcp_ctx, oracle, metric):
         g = vcp_ctx.dbscan(c, 0.1, 12, metric, **kw)
         _same(g, o)
         assert np.array_equal(g["is_core"], o["is_key"])
+
+
+@pytest.mark.parametrize("metric", [N.L1_2D, N.L2_3D])
+def test_coarsened_grid_and_far_outliers(vcp_ctx, oracle, metric):
+    """Extent >> eps: the cell budget coarsens the grid (cells of many eps), tiny eps against huge coordinates,
+    a few outliers 10^9 away, and an axis with zero extent."""
+    rng = np.random.default_rng(90 + metric)
+    dim = 3 if metric == N.L2_3D else 2
+    n = 20_000
+    c = np.round(rng.normal(0, 50.0, (n, dim)) * 1024) / 1024
+    c[:2000] = np.round(rng.normal(5.0, 0.01, (2000, dim)) * 65536) / 65536     # a tight clump: eps-scale structure
+    c[2000:2010] = rng.uniform(-1e9, 1e9, (10, dim))                              # far outliers stretch the bounds
+    for eps in (0.002, 0.05):
+        o = oracle.dbscan(c, eps, 5, metric)
+        g = vcp_ctx.dbscan(c, eps, 5, metric)
+        _same(g, o, "eps %g" % eps)
+        assert g["cf"] >= 1
+    flat = c.copy()
+    flat[:, 1] = 7.0                                                              # zero extent in y
+    _same(vcp_ctx.dbscan(flat, 0.05, 5, metric), oracle.dbscan(flat, 0.05, 5, metric), "flat axis")
+    big = c[:5000] + 1e12                                                         # eps far below one ulp spacing issues
+    _same(vcp_ctx.dbscan(big, 0.05, 5, metric), oracle.dbscan(big, 0.05, 5, metric), "offset 1e12")

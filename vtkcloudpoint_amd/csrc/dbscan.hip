@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <vector>
 
 #include <rocprim/rocprim.hpp>
 
@@ -208,6 +209,50 @@ __global__ __launch_bounds__(TPB) void k_bounds_final(const double* __restrict__
     bad += partial[b * 8 + 6];
   }
   block_minmax(mn, mx, bad, out);
+}
+
+// Trimmed moments for a robust grid range: per axis the count, sum and sum of squares (about mid[a]) of the
+// finite values inside [lo[a], hi[a]].  partial[b*9 + 3*a + {0,1,2}].  Only used when the eps-grid over the full
+// bounding box would not fit the cell budget (a few far outliers would otherwise coarsen the grid for everybody).
+struct Range3 {
+  double lo[3], hi[3], mid[3];
+};
+template <int GD, bool GROUPED>
+__global__ __launch_bounds__(TPB) void k_moments(const double* __restrict__ c, int64_t n, int stride,
+                                                const int32_t* __restrict__ group, int glo, int ghi, Range3 R,
+                                                double* __restrict__ partial) {
+  double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+    if (GROUPED) {
+      int g = group[i];
+      if (g < glo || g >= ghi) continue;
+    }
+#pragma unroll
+    for (int a = 0; a < GD; a++) {
+      const double v = c[i * stride + a];
+      if (v >= R.lo[a] && v <= R.hi[a]) {
+        const double d = v - R.mid[a];
+        m[3 * a] += 1.0;
+        m[3 * a + 1] += d;
+        m[3 * a + 2] += d * d;
+      }
+    }
+  }
+  __shared__ double sm[TPB / 64][9];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    double v = m[k];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+    if (lane == 0) sm[w][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 9) {
+    double v = sm[0][threadIdx.x];
+    for (int k = 1; k < TPB / 64; k++) v += sm[k][threadIdx.x];
+    partial[(size_t)blockIdx.x * 9 + threadIdx.x] = v;
+  }
 }
 
 // ---- grid build -------------------------------------------------------------------------------
@@ -1295,12 +1340,66 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
     range = std::fmax(range, hi - lo);
   }
   double cellw = eps * (1.0 + 1.0 / 1048576.0);
-  const double min_w = range / 1048575.0;
-  if (!(cellw >= min_w)) cellw = min_w;
-  if (!(cellw > 0.0)) cellw = 1.0;
   int64_t budget = n * 32;
   if (budget < (1 << 16)) budget = 1 << 16;
   if (budget > ((int64_t)1 << 31) - 16) budget = ((int64_t)1 << 31) - 16;  // cell ids and ncells + 1 stay in 31 bits
+  // Robust range.  Cell indices are clamped to the grid, so ANY origin and extent give correct results (a point
+  // beyond the grid shares the edge cell with its neighbours); the full bounding box is only the natural choice.
+  // When the eps-grid over it does not fit the budget, the range is trimmed to mean +- 8 sigma of the points
+  // inside it, repeatedly: a handful of far outliers then end up in the edge cells instead of coarsening the
+  // grid for the whole cloud.
+  {
+    auto cells_needed = [&](const double* lo, const double* hi) {
+      double c = 1.0;
+      for (int a = 0; a < GD; a++) c *= std::floor((hi[a] - lo[a]) / cellw) + 1.0;
+      return c;
+    };
+    double lo[3] = {h[0], h[1], h[2]}, hi[3] = {h[3], h[4], h[5]};
+    for (int it = 0; it < 8 && cellw > 0.0 && std::isfinite(cellw) && !(cells_needed(lo, hi) <= (double)budget); it++) {
+      Range3 R;
+      for (int a = 0; a < 3; a++) {
+        R.lo[a] = lo[a];
+        R.hi[a] = hi[a];
+        R.mid[a] = 0.5 * lo[a] + 0.5 * hi[a];
+      }
+      VCP_TRY(vcp_ensure(ctx, ctx->b_aux0, (size_t)rb * 9 * sizeof(double)));
+      double* d_mom = ctx->b_aux0.as<double>();
+      hipLaunchKernelGGL((k_moments<GD, GROUPED>), dim3(rb), dim3(TPB), 0, st, d_coords, n, stride, d_group, glo, ghi, R,
+                         d_mom);
+      std::vector<double> hm((size_t)rb * 9);
+      VCP_HIP(ctx, hipMemcpyAsync(hm.data(), d_mom, hm.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      VCP_HIP(ctx, hipStreamSynchronize(st));
+      bool changed = false;
+      for (int a = 0; a < GD; a++) {
+        double cnt = 0, s1 = 0, s2 = 0;
+        for (int b = 0; b < rb; b++) {
+          cnt += hm[(size_t)b * 9 + 3 * a];
+          s1 += hm[(size_t)b * 9 + 3 * a + 1];
+          s2 += hm[(size_t)b * 9 + 3 * a + 2];
+        }
+        if (!(cnt > 0)) continue;
+        const double mean = s1 / cnt, var = std::fmax(s2 / cnt - mean * mean, 0.0);
+        const double c0 = R.mid[a] + mean, w = 8.0 * std::sqrt(var) + 4.0 * cellw;
+        const double nlo = std::fmax(lo[a], c0 - w), nhi = std::fmin(hi[a], c0 + w);
+        if (nlo > lo[a] || nhi < hi[a]) changed = true;
+        if (nlo <= nhi) {
+          lo[a] = nlo;
+          hi[a] = nhi;
+        }
+      }
+      if (!changed) break;
+    }
+    for (int a = 0; a < GD; a++) {
+      h[a] = lo[a];
+      h[3 + a] = hi[a];
+      g.mn[a] = lo[a];
+    }
+    range = 0.0;
+    for (int a = 0; a < GD; a++) range = std::fmax(range, h[3 + a] - h[a]);
+  }
+  const double min_w = range / 1048575.0;
+  if (!(cellw >= min_w)) cellw = min_w;
+  if (!(cellw > 0.0)) cellw = 1.0;
   int64_t ncells = 0;
   for (int it = 0; it < 400; it++) {
     ncells = 1;

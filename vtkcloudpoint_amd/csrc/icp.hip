@@ -35,7 +35,7 @@ struct IcpState {
   double R[9], T[3];
   double d, pre_d;
   double sums[16];
-  double dmax, mmax;  // largest |coordinate| of data / model: scale of the binary32 screening bound
+  double cen[3], mmax;  // centre of the model's bounding box and its half extent: frame and scale of the screening
   int round, done, failed, pad;
 };
 
@@ -45,24 +45,62 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// largest |v| of an array into *out (the bit pattern of a non-negative double orders like the value)
-__global__ __launch_bounds__(ITPB) void k_absmax(const double* __restrict__ a, int64_t n, double* __restrict__ out) {
-  double m = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * ITPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * ITPB) {
-    double v = fabs(a[i]);
-    if (!(v <= m)) m = (v == v) ? v : INFINITY;  // NaN -> infinite scale (everything is re-checked in binary64)
-  }
+// bounding box of the model -> centre and half extent in the state (single workgroup: models are small).  A model
+// with non-finite coordinates gets an infinite scale: every data point is then resolved in binary64.
+__global__ __launch_bounds__(ITPB) void k_model_frame(const double* __restrict__ m, int64_t nm, IcpState* __restrict__ st) {
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  bool bad = false;
+  for (int64_t j = threadIdx.x; j < nm; j += ITPB) {
 #pragma unroll
-  for (int d = 32; d > 0; d >>= 1) m = fmax(m, __shfl_down(m, d, 64));
-  if ((threadIdx.x & 63) == 0)
-    atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(m));
+    for (int a = 0; a < 3; a++) {
+      const double v = m[3 * j + a];
+      if (!(fabs(v) <= 1.7976931348623157e308)) bad = true;
+      lo[a] = fmin(lo[a], v);
+      hi[a] = fmax(hi[a], v);
+    }
+  }
+  __shared__ double sl[ITPB / 64][3], sh[ITPB / 64][3];
+  __shared__ int sbad;
+  if (threadIdx.x == 0) sbad = 0;
+  __syncthreads();
+  if (bad) sbad = 1;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    double l = lo[a], h = hi[a];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      l = fmin(l, __shfl_down(l, d, 64));
+      h = fmax(h, __shfl_down(h, d, 64));
+    }
+    if (lane == 0) {
+      sl[w][a] = l;
+      sh[w][a] = h;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double mm = 0.0;
+    for (int a = 0; a < 3; a++) {
+      double l = sl[0][a], h = sh[0][a];
+      for (int k = 1; k < ITPB / 64; k++) {
+        l = fmin(l, sl[k][a]);
+        h = fmax(h, sh[k][a]);
+      }
+      const double c = 0.5 * l + 0.5 * h;
+      st->cen[a] = sbad ? 0.0 : c;
+      mm = fmax(mm, fmax(h - c, c - l));
+    }
+    st->mmax = sbad ? INFINITY : mm;
+  }
 }
 
-// screening copy of the model: (m0, m1, m2, |m|^2 / 2) in binary32, one 16-byte scalar load per model point
-__global__ __launch_bounds__(ITPB) void k_model32(const double* __restrict__ m, int64_t nm, float4* __restrict__ o) {
+// screening copy of the model in the centred frame: (m - c, |m - c|^2 / 2) in binary32, one 16-byte load per point
+__global__ __launch_bounds__(ITPB) void k_model32(const double* __restrict__ m, int64_t nm, const IcpState* __restrict__ st,
+                                                 float4* __restrict__ o) {
   int64_t j = (int64_t)blockIdx.x * ITPB + threadIdx.x;
   if (j >= nm) return;
-  const double a = m[3 * j], b = m[3 * j + 1], c = m[3 * j + 2];
+  const double a = m[3 * j] - st->cen[0], b = m[3 * j + 1] - st->cen[1], c = m[3 * j + 2] - st->cen[2];
   o[j] = make_float4((float)a, (float)b, (float)c, (float)(0.5 * (a * a + b * b + c * c)));
 }
 
@@ -84,13 +122,13 @@ __global__ __launch_bounds__(TB) void k_icp_pass(const double* __restrict__ mode
   for (int k = 0; k < 9; k++) R[k] = st->R[k];
 #pragma unroll
   for (int k = 0; k < 3; k++) T[k] = st->T[k];
-  // binary32 screening on the score h_j - q.m_j (= (|q - m_j|^2 - |q|^2) / 2, h_j = |m_j|^2 / 2): three FMAs per
-  // model point.  With S = a bound on every |coordinate| involved and u = 2^-24 the computed score is within
-  // 27 u S^2 of the exact one (input conversions 9 u S^2, h_j 4.5 u S^2, three fused roundings 13.5 u S^2), so a
-  // model point can be the binary64 winner only if score <= best score + 54 u S^2; 2^-17 S^2 = 128 u S^2 is used.
-  const double tmax = fmax(fabs(T[0]), fmax(fabs(T[1]), fabs(T[2])));
-  const double S = fmax(st->mmax, tmax + 3.0 * st->dmax);
-  const float tol2 = (float)(S * S * 7.62939453125e-06) * 1.0001f;  // 2^-17 S^2, rounded up
+  // binary32 screening on the score h_j - q.m_j (= (|q - m_j|^2 - |q|^2) / 2, h_j = |m_j|^2 / 2), q and m taken
+  // relative to the centre of the model's bounding box (the score differences are translation invariant): three
+  // FMAs per model point.  With S = a bound on every |coordinate| involved (this lane's |q - c| and the model's half
+  // extent) and u = 2^-24 the computed score is within 27 u S^2 of the exact one (input conversions 9 u S^2, h_j
+  // 4.5 u S^2, three fused roundings 13.5 u S^2), so a model point can be the binary64 winner only if
+  // score <= best score + 54 u S^2; 2^-17 S^2 = 128 u S^2 is used.  The bound is per data point.
+  const double cen0 = st->cen[0], cen1 = st->cen[1], cen2 = st->cen[2], mmax = st->mmax;
   double s[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) s[k] = 0.0;
@@ -109,7 +147,10 @@ __global__ __launch_bounds__(TB) void k_icp_pass(const double* __restrict__ mode
       acc += R[3 * r + 2] * d2;
       p[r] = acc + T[r];
     }
-    const float q0 = (float)p[0], q1 = (float)p[1], q2 = (float)p[2];
+    const double pc0 = p[0] - cen0, pc1 = p[1] - cen1, pc2 = p[2] - cen2;
+    const float q0 = (float)pc0, q1 = (float)pc1, q2 = (float)pc2;
+    const double S = fmax(mmax, fmax(fabs(pc0), fmax(fabs(pc1), fabs(pc2))));
+    const float tol2 = (float)(S * S * 7.62939453125e-06) * 1.0001f;  // 2^-17 S^2, rounded up (NaN -> all candidates)
     // pass 1 (binary32): smallest and second smallest screened score, four model points per trip
     float b1 = INFINITY, b2 = INFINITY;
     int j1 = 0;
@@ -460,9 +501,8 @@ int icp_run(vcp_ctx* ctx, const double* d_model, int64_t nm, const double* d_dat
   IcpState* h_st = reinterpret_cast<IcpState*>(ctx->pinned);
   *h_st = init;
   VCP_HIP(ctx, hipMemcpyAsync(d_st, h_st, sizeof(IcpState), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_absmax, dim3(vcp_blocks(nd * 3, ITPB, 512)), dim3(ITPB), 0, st, d_data, nd * 3, &d_st->dmax);
-  hipLaunchKernelGGL(k_absmax, dim3(vcp_blocks(nm * 3, ITPB, 64)), dim3(ITPB), 0, st, d_model, nm * 3, &d_st->mmax);
-  hipLaunchKernelGGL(k_model32, dim3(vcp_blocks(nm, ITPB)), dim3(ITPB), 0, st, d_model, nm, model32);
+  hipLaunchKernelGGL(k_model_frame, dim3(1), dim3(ITPB), 0, st, d_model, nm, d_st);
+  hipLaunchKernelGGL(k_model32, dim3(vcp_blocks(nm, ITPB)), dim3(ITPB), 0, st, d_model, nm, d_st, model32);
   int launched = 0;
   for (;;) {
     const int batch = mode == MODE_SUMS_ONLY ? 1 : std::min(ICP_BATCH, max_iter - launched);

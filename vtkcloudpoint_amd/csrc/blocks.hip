@@ -30,7 +30,7 @@ struct BlocksState {
   double eps = 0;
   int min_pts = 0, small_max = 3, take = 0;
   double x_Min = 0, x_Max = 0, y_Min = 0, y_Max = 0, cell_x = 0, cell_y = 0;
-  DevBuf motor, raw, rankpos, blockof, bl, bpos, blockstart, lab_orig, gtwice, gnclus, tmp0, tmp1, tmp2, tmp3, sorttmp,
+  DevBuf motor, raw, rankpos, blockof, bl, motor_bm, blockstart, gtwice, gnclus, tmp0, tmp1, tmp2, tmp3, sorttmp,
       blk_t, csize, cstart, kb, zb, keep, order, newlab, zflag, zlist, zcoords, zlab, misc;
   std::vector<uint32_t> h_blockstart;
   bool ready = false;
@@ -276,10 +276,12 @@ __global__ __launch_bounds__(BT) void k_mark_key_ends(const uint32_t* __restrict
   if (t == n - 1 || skey[t + 1] != k) mark[k] = (uint32_t)t + 1u;
 }
 
-__global__ __launch_bounds__(BT) void k_gather_local(const int32_t* __restrict__ lab_orig, const uint32_t* __restrict__ bl,
-                                                    uint32_t lo, uint32_t hi, int32_t* __restrict__ local) {
-  int64_t t = (int64_t)blockIdx.x * BT + threadIdx.x + lo;
-  if (t < hi) local[t] = lab_orig[bl[t]];
+// the cloud in block-major order: the per-block clustering then reads and writes by block-major position (the
+// engine's gather becomes spatially coherent, its labels ARE the block-local ids in list order)
+__global__ __launch_bounds__(BT) void k_gather_motor(const double* __restrict__ motor, const uint32_t* __restrict__ bl,
+                                                    int64_t m, double* __restrict__ motor_bm) {
+  int64_t t = (int64_t)blockIdx.x * BT + threadIdx.x;
+  if (t < m) *reinterpret_cast<double2*>(motor_bm + 2 * t) = *reinterpret_cast<const double2*>(motor + 2 * (int64_t)bl[t]);
 }
 
 // ---- finish --------------------------------------------------------------------------------------
@@ -502,7 +504,7 @@ int blocks_begin(vcp_ctx* ctx, const double* d_motor_in, bool from_host, const d
   const int64_t nb1 = s->nblocks + 1;
   VCP_TRY(ens(ctx, s->blockstart, (size_t)(nb1 + 1) * 4));
   VCP_TRY(ens(ctx, s->bl, (size_t)n * 4));
-  VCP_TRY(ens(ctx, s->bpos, (size_t)n * 4));
+  VCP_TRY(ens(ctx, s->motor_bm, (size_t)n * 16));
   uint32_t* bkey = s->tmp2.as<uint32_t>();
   VCP_TRY(ens(ctx, s->blk_t, (size_t)(n + 1) * 4));
   uint32_t* blk_t = s->blk_t.as<uint32_t>();  // block id per block-major position (the sorted keys)
@@ -513,14 +515,14 @@ int blocks_begin(vcp_ctx* ctx, const double* d_motor_in, bool from_host, const d
   VCP_HIP(ctx, hipMemsetAsync(s->blockstart.p, 0, (size_t)(nb1 + 1) * 4, st));
   hipLaunchKernelGGL(k_mark_key_ends, dim3(nblk(n)), dim3(BT), 0, st, blk_t, n, s->blockstart.as<uint32_t>());
   VCP_TRY(vcp_exclusive_max_scan_u32(ctx, s->blockstart.as<uint32_t>(), s->blockstart.as<uint32_t>(), nb1 + 1, nullptr));
-  hipLaunchKernelGGL(k_inverse, dim3(nblk(n)), dim3(BT), 0, st, s->bl.as<uint32_t>(), n, s->bpos.as<uint32_t>());
+  hipLaunchKernelGGL(k_gather_motor, dim3(nblk(n)), dim3(BT), 0, st, motor, s->bl.as<uint32_t>(), n,
+                     s->motor_bm.as<double>());
   VCP_HIP(ctx, hipGetLastError());
   s->h_blockstart.resize((size_t)nb1 + 1);
   VCP_HIP(ctx, hipMemcpyAsync(s->h_blockstart.data(), s->blockstart.p, (size_t)(nb1 + 1) * 4, hipMemcpyDeviceToHost, st));
   VCP_HIP(ctx, hipStreamSynchronize(st));
   s->m = s->h_blockstart[(size_t)s->nblocks];
   if (m_o) *m_o = s->m;
-  VCP_TRY(ens(ctx, s->lab_orig, (size_t)n * 4));
   VCP_TRY(ens(ctx, s->gtwice, (size_t)nb1 * 4));
   VCP_TRY(ens(ctx, s->gnclus, (size_t)nb1 * 4));
   s->ready = true;
@@ -534,9 +536,10 @@ int blocks_cluster(vcp_ctx* ctx, int32_t lo, int32_t hi, int32_t* d_local, int64
   if (lo < 0 || hi > s->nblocks || lo > hi) return vcp_fail(ctx, VCP_ERR_ARG, "block range");
   if (evals_o) *evals_o = 0;
   if (lo == hi) return VCP_OK;
+  if (s->m == 0) return VCP_OK;
   DbscanExt ext;
-  ext.d_group = s->blockof.as<int32_t>();
-  ext.d_ord = s->bpos.as<uint32_t>();
+  ext.d_group = reinterpret_cast<const int32_t*>(s->blk_t.as<uint32_t>());  // block id per block-major position
+  ext.d_ord = nullptr;                                                        // list position = input index
   ext.d_groupstart = s->blockstart.as<uint32_t>();
   ext.G = (int32_t)s->nblocks;
   ext.only_lo = lo;
@@ -545,12 +548,9 @@ int blocks_cluster(vcp_ctx* ctx, int32_t lo, int32_t hi, int32_t* d_local, int64
   ext.d_group_nclus = s->gnclus.as<uint32_t>();
   int64_t ev = 0;
   int32_t cf = 0;
-  VCP_TRY(vcp_dbscan_engine(ctx, s->motor.as<double>(), s->n, 2, VCP_L1_2D, s->eps, s->min_pts, 0, nullptr,
-                            s->lab_orig.as<int32_t>(), nullptr, nullptr, &cf, &ev, &ext));
-  const uint32_t plo = s->h_blockstart[(size_t)lo], phi = s->h_blockstart[(size_t)hi];
-  if (phi > plo)
-    hipLaunchKernelGGL(k_gather_local, dim3(nblk(phi - plo)), dim3(BT), 0, ctx->stream, s->lab_orig.as<int32_t>(),
-                       s->bl.as<uint32_t>(), plo, phi, d_local);
+  // input = the m points that fell in a block, in block-major order; positions outside [lo, hi)'s slice get 0
+  VCP_TRY(vcp_dbscan_engine(ctx, s->motor_bm.as<double>(), s->m, 2, VCP_L1_2D, s->eps, s->min_pts, 0, nullptr, d_local,
+                            nullptr, nullptr, &cf, &ev, &ext));
   VCP_HIP(ctx, hipGetLastError());
   VCP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (evals_o) *evals_o = ev;
@@ -668,7 +668,7 @@ extern "C" {
 void vcp_blocks_state_free(vcp_ctx* ctx) {
   if (!ctx || !ctx->blocks) return;
   BlocksState* s = ctx->blocks;
-  DevBuf* all[] = {&s->motor, &s->raw, &s->rankpos, &s->blockof, &s->bl, &s->bpos, &s->blockstart, &s->lab_orig,
+  DevBuf* all[] = {&s->motor, &s->raw, &s->rankpos, &s->blockof, &s->bl, &s->motor_bm, &s->blockstart,
                    &s->gtwice, &s->gnclus, &s->tmp0, &s->tmp1, &s->tmp2, &s->tmp3, &s->sorttmp, &s->blk_t, &s->csize,
                    &s->cstart, &s->kb, &s->zb, &s->keep, &s->order, &s->newlab, &s->zflag, &s->zlist, &s->zcoords,
                    &s->zlab, &s->misc};

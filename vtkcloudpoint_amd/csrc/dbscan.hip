@@ -1067,7 +1067,9 @@ __global__ __launch_bounds__(TPB) void k_output(int64_t n, const uint32_t* __res
   (void)counters;
   if (i < n) {
     const uint32_t p = pos[i];
-    if (p == NONE) {  // excluded from this call
+    if (p == NONE) {  // excluded from this call (grouped: outside the group range -- left untouched, another
+                      // call or another rank owns that slice of the label array)
+      if (GROUPED) return;
       if (!in_classed) labels[i] = 0;
       if (is_core) is_core[i] = 0;
       if (is_classed) is_classed[i] = in_classed ? in_classed[i] : 0;
@@ -1669,8 +1671,8 @@ int vcp_dbscan_engine(vcp_ctx* ctx, const double* d_coords, int64_t n, int strid
   if (n >= 0x3FFFFFF0LL) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "n beyond 30-bit indexing");
   if (n > 0 && (!d_coords || !d_labels)) return vcp_fail(ctx, VCP_ERR_ARG, "null buffer");
   const bool grouped = ext && ext->d_group;
-  if (grouped && (metric != VCP_L1_2D || !ext->d_ord || !ext->d_groupstart || !ext->d_group_twice || d_in_classed))
-    return vcp_fail(ctx, VCP_ERR_ARG, "grouped DBSCAN needs ord, groupstart, group_twice and the L1 metric");
+  if (grouped && (metric != VCP_L1_2D || !ext->d_groupstart || !ext->d_group_twice || d_in_classed))
+    return vcp_fail(ctx, VCP_ERR_ARG, "grouped DBSCAN needs groupstart, group_twice and the L1 metric");
   VCP_TRY(vcp_bind(ctx));
   vcp_phase_reset(ctx);
   if (ctx->slab) ctx->slab->valid = false;  // the workspace is about to be overwritten

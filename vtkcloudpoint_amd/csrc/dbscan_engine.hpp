@@ -8,7 +8,7 @@
 // groupstart[g] the first ord of group g.  Cluster ids restart at cf_in+1 in every group.
 struct DbscanExt {
   const int32_t* d_group = nullptr;        // [n] by original index; < 0 = point excluded entirely
-  const uint32_t* d_ord = nullptr;         // [n] by original index
+  const uint32_t* d_ord = nullptr;         // [n] by original index (NULL = the index itself)
   const uint32_t* d_groupstart = nullptr;  // [G+1]
   int32_t G = 0;
   int32_t only_lo = 0, only_hi = -1;       // cluster only groups lo <= g < hi (-1 = G)

@@ -291,14 +291,56 @@ __global__ __launch_bounds__(TPB) void k_cell_key(const double* __restrict__ c, 
   key[i] = cell_of<GD>(q, g, cc);
 }
 
-// mark[k] = (last position of cell k) + 1; an exclusive max-scan of the marks is the first position of each cell
-__global__ __launch_bounds__(TPB) void k_mark_ends(const uint32_t* __restrict__ skey, int64_t n, uint32_t ncells,
-                                                  uint32_t* __restrict__ mark) {
+// Cell starts from the sorted keys, tile by tile.  The table has ~5 entries per point on sparse clouds, so it is
+// written exactly once and never zero-filled or scanned in global memory: the keys of a tile of CTILE consecutive
+// cells are counted in LDS, scanned there, and the tile's slice of the table is stored coalesced.  Which keys
+// belong to a tile comes from marks of the tile ends in the key list + a max-scan over the (few) tiles.
+constexpr int CTILE = 8192;
+__global__ __launch_bounds__(TPB) void k_tile_marks(const uint32_t* __restrict__ skey, int64_t n, uint32_t* __restrict__ tmark) {
   int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
   if (p >= n) return;
-  const uint32_t k = skey[p];
-  if (k >= ncells) return;
-  if (p == n - 1 || skey[p + 1] != k) mark[k] = (uint32_t)p + 1u;
+  const uint32_t t = skey[p] / CTILE;
+  if (p == n - 1 || skey[p + 1] / CTILE != t) tmark[t] = (uint32_t)p + 1u;
+}
+__global__ __launch_bounds__(TPB) void k_cellstart_tiles(const uint32_t* __restrict__ skey, const uint32_t* __restrict__ tilestart,
+                                                        uint32_t ncells, uint32_t* __restrict__ cellstart) {
+  // one pad word per 32 counters: a thread's run of 32 consecutive counters then walks all banks
+  __shared__ uint32_t cnt[CTILE + CTILE / 32];
+  __shared__ uint32_t wsum[TPB / 64];
+  auto at = [](int i) { return i + (i >> 5); };
+  const uint32_t c0 = blockIdx.x * (uint32_t)CTILE;
+  const uint32_t p_lo = tilestart[blockIdx.x], p_hi = tilestart[blockIdx.x + 1];
+  for (int k = threadIdx.x; k < CTILE + CTILE / 32; k += TPB) cnt[k] = 0;
+  __syncthreads();
+  for (uint32_t p = p_lo + threadIdx.x; p < p_hi; p += TPB) atomicAdd(&cnt[at((int)(skey[p] - c0))], 1u);
+  __syncthreads();
+  // exclusive scan of the CTILE counters: thread t owns CTILE / TPB consecutive ones
+  constexpr int PER = CTILE / TPB;
+  const int base = threadIdx.x * PER;
+  uint32_t loc = 0;
+#pragma unroll 8
+  for (int k = 0; k < PER; k++) loc += cnt[at(base + k)];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t inc = loc;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  uint32_t pre = p_lo + inc - loc;
+  for (int k = 0; k < w; k++) pre += wsum[k];
+#pragma unroll 8
+  for (int k = 0; k < PER; k++) {
+    const uint32_t v = cnt[at(base + k)];
+    cnt[at(base + k)] = pre;
+    pre += v;
+  }
+  __syncthreads();
+  // coalesced store; cells up to and including index ncells (= number of included points) exist in the table
+  for (int k = threadIdx.x; k < CTILE; k += TPB)
+    if (c0 + (uint32_t)k <= ncells) cellstart[c0 + k] = cnt[at(k)];
 }
 
 template <int GD, bool GROUPED>
@@ -1471,9 +1513,13 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
     VCP_TRY(vcp_ensure(ctx, ctx->b_sorttmp, tb));
     VCP_HIP(ctx, rocprim::radix_sort_pairs(ctx->b_sorttmp.p, tb, cellof, skey, vals_in, sidx, (size_t)n, 0, bits, st));
     vcp_phase(ctx, "cell_scan");
-    VCP_HIP(ctx, hipMemsetAsync(cellcnt, 0, (size_t)(ncells + 1) * 4, st));
-    hipLaunchKernelGGL(k_mark_ends, dim3(nb), dim3(TPB), 0, st, skey, n, g.ncells, cellcnt);
-    VCP_TRY(vcp_exclusive_max_scan_u32(ctx, cellcnt, cellcnt, ncells + 1, nullptr));
+    const int64_t ntiles = (ncells + 1 + CTILE - 1) / CTILE;  // the table has ncells + 1 entries
+    VCP_TRY(vcp_ensure(ctx, ctx->b_aux0, (size_t)(ntiles + 2) * 4));
+    uint32_t* tilestart = ctx->b_aux0.as<uint32_t>();
+    VCP_HIP(ctx, hipMemsetAsync(tilestart, 0, (size_t)(ntiles + 2) * 4, st));
+    hipLaunchKernelGGL(k_tile_marks, dim3(nb), dim3(TPB), 0, st, skey, n, tilestart);
+    VCP_TRY(vcp_exclusive_max_scan_u32(ctx, tilestart, tilestart, ntiles + 1, nullptr));
+    hipLaunchKernelGGL(k_cellstart_tiles, dim3((unsigned)ntiles), dim3(TPB), 0, st, skey, tilestart, g.ncells, cellcnt);
     vcp_phase(ctx, "scatter");
     if (!d_in_classed) VCP_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)n, st));
     hipLaunchKernelGGL((k_gather<GD, GROUPED>), dim3(nb), dim3(TPB), 0, st, d_coords, stride, cellcnt, g.ncells, sidx,

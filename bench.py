@@ -29,7 +29,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 # Algorithmic bytes per point of each kernel phase for the 2-D binary64 path:
 # what the phase must read/write once if every neighbour access hits cache.
 ALGO_BYTES_PER_POINT = {
-    "bounds": 16, "cell_key": 24, "cell_sort": 48, "cell_scan": 6, "scatter": 48, "core_count": 18, "union": 25,
+    "bounds": 16, "cell_key": 24, "cell_sort": 48, "cell_scan": 24, "scatter": 48, "core_count": 18, "union": 25,
     "flatten_number": 24, "border": 21, "output": 14,
 }
 

@@ -19,7 +19,7 @@ from collections import defaultdict
 
 PHASE_OF = {
     "k_bounds": "bounds", "k_bounds_final": "bounds", "k_cell_key": "cell_key", "rocprim_radix_sort": "cell_sort",
-    "k_mark_ends": "cell_scan", "k_gather": "scatter",
+    "k_tile_marks": "cell_scan", "k_cellstart_tiles": "cell_scan", "k_gather": "scatter",
     "k_scan_tile_sums": "cell_scan", "k_scan_offsets": "cell_scan", "k_scan_tiles": "cell_scan",
     "k_core": "core_count", "k_core_lds": "core_count", "k_wl_fill": "core_count",
     "k_union": "union", "k_union_init": "union", "k_flatten0": "union", "k_init_parent": "union",

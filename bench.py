@@ -157,7 +157,11 @@ def main():
     elif world > 1:
         # slabs clustered independently, ids made global on the device, int32 labels all-gathered over RCCL on a
         # second communicator so that the gather of step k overlaps the clustering of step k+1 (double buffered)
-        big = dist.new_group(backend="nccl")
+        try:
+            big = dist.new_group(backend="nccl")
+        except Exception as e:  # a second communicator is an optimisation, not a requirement
+            print("bench: second RCCL communicator unavailable (%s); gathering on the default group" % e, file=sys.stderr)
+            big = None
         pipe = D.SlabPipeline(ctx, n, dev, depth=2, group=None, big_group=big)
 
     def step(record):

@@ -724,14 +724,16 @@ __device__ __forceinline__ uint32_t ld_parent_cached(const uint32_t* parent, uin
   return __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
-#ifndef VCP_ROOT_CACHED
-#define VCP_ROOT_CACHED 1
-#endif
-__device__ __forceinline__ uint32_t uf_root(const uint32_t* parent, uint32_t x) {
-  uint32_t p = VCP_ROOT_CACHED ? ld_parent_cached(parent, x) : ld_parent(parent, x);
+// find with path halving: every other node on the way is re-pointed at its grandparent (an ancestor, so the
+// pointers still only decrease and any interleaving stays a forest); later finds through these nodes are shorter
+__device__ __forceinline__ uint32_t uf_root(uint32_t* parent, uint32_t x) {
+  uint32_t p = ld_parent_cached(parent, x);
   while (p != x) {
-    x = p;
-    p = VCP_ROOT_CACHED ? ld_parent_cached(parent, x) : ld_parent(parent, x);
+    const uint32_t gp = ld_parent_cached(parent, p);
+    if (gp == p) return p;
+    __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    x = gp;
+    p = ld_parent_cached(parent, x);
   }
   return x;
 }

@@ -79,7 +79,12 @@ def cpu_baseline(cloud, coords, eps, min_pts, metric_id, budget_s=18.0):
     t0 = time.time()
     r2 = O.dbscan(crop2, eps, min_pts, metric_id, literal=False)
     dt2 = time.time() - t0
+    import shutil
+    toolchain = [t for t in ("dotnet", "mono", "csc", "mcs") if shutil.which(t)]
     return {
+        # the real C# could only be timed where a .NET toolchain AND the reference sources exist; the
+        # sources never travel to the GPU box, so this stays a record of what the box offers
+        "csharp_toolchain_on_this_host": toolchain,
         "grid_port": {"value": len(crop2) / dt2 / 1e6, "unit": "Mpoints/s", "cores": 1,
                       "sample": "oracle's canonical grid formulation (same results as the literal port) on the %d "
                                 "nearest points: %.1f s, %d clusters" % (len(crop2), dt2, r2["cf"])},

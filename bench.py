@@ -45,6 +45,10 @@ def parse():
                     help="N>1: 'slabs' = every rank clusters its own cloud independently (ids made global, labels "
                          "all-gathered); 'exact' = the ranks' clouds are adjacent x-slabs of ONE cloud and the result is "
                          "the monolithic DBImproved.dbscan over all of it (halo exchange + boundary union)")
+    ap.add_argument("--gather-labels", action="store_true",
+                    help="N>1, mode slabs: also all-gather every rank's int32 labels onto every rank (40 MB per rank and "
+                         "step at 10 M points, overlapped with the next step on a second communicator); by default the "
+                         "labels stay on the rank that owns the slab and only the cluster counts are exchanged")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the ICP / L2_3D side measurements")
     return ap.parse_args()
@@ -159,7 +163,7 @@ def main():
                 self.log += self.c.timing()
                 return r
         timed = Timed(ctx)
-    elif world > 1:
+    elif world > 1 and args.gather_labels:
         # slabs clustered independently, ids made global on the device, int32 labels all-gathered over RCCL on a
         # second communicator so that the gather of step k overlaps the clustering of step k+1 (double buffered)
         try:
@@ -178,9 +182,13 @@ def main():
                     phase_ms.setdefault(name, []).append(ms)
                 phase_ms.setdefault("halo_points", []).append(r["halo"])
             return r["cf"], r["dist_evals"]
-        if world > 1:
+        if world > 1 and pipe is not None:
             allc, ev, _ = pipe.step(d_coords, dim, eps, min_pts, metric_id)
             cf = allc
+        elif world > 1:
+            # independent slabs: cluster, exchange the cluster counts (8 bytes per rank), make the ids global on the
+            # device; the labels stay on the owning rank
+            cf, ev = D.slab_cluster(ctx, d_coords, n, dim, eps, min_pts, metric_id, d_labels, None, None)
         else:
             cf, ev = ctx.dbscan_dev(d_coords.data_ptr(), n, dim, eps, min_pts, metric_id, 0, None,
                                     d_labels.data_ptr(), d_core.data_ptr(), d_cls.data_ptr())
@@ -255,7 +263,9 @@ def main():
                             % (n, n // 50_000, args.metric, eps, min_pts,
                                "; ranks own adjacent x-slabs of one cloud, exact global result (2*eps halo + boundary "
                                "union over RCCL, labels stay on the owning rank)" if exact else
-                               "; slabs per rank + RCCL all-gather of int32 labels" if world > 1 else ""),
+                               "; slabs per rank + RCCL all-gather of int32 labels" if (world > 1 and pipe is not None) else
+                               "; one slab per rank, cluster ids made global through an RCCL all-gather of the per-rank "
+                               "counts, labels stay on the owning rank" if world > 1 else ""),
                 "points_per_gpu": n,
                 "clusters": int(cf) if (exact or world == 1) else int(cf.sum().item()), "resident_in_hbm": True,
                 "mode": args.mode if (world > 1 or exact) else "single",

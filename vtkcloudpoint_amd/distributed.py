@@ -110,6 +110,8 @@ def slab_cluster(ctx, d_coords, n, dim, eps, min_pts, metric, d_labels, gathered
     all-gather the labels into `gathered` [world*n] if given.  The renumbering stays on the device (no host
     round trip between the clustering and the all-gather).  Returns (per-rank cluster counts tensor, evals)."""
     rank, world = _world(group)
+    if d_labels.is_cuda:  # the library writes on its own stream: whatever torch still has queued on these buffers
+        torch.cuda.current_stream(d_labels.device).synchronize()  # (the previous step's renumbering) must be done
     cf, ev = ctx.dbscan_dev(d_coords.data_ptr(), n, dim, eps, min_pts, metric, 0, None, d_labels.data_ptr())
     dev = d_labels.device
     mine = torch.tensor([cf], dtype=torch.int64, device=dev)

@@ -64,6 +64,11 @@ int vcp_dev_free(vcp_ctx* ctx, void* dptr);
 int vcp_h2d(vcp_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
 int vcp_d2h(vcp_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
 
+/* The context keeps its device workspace between calls (no hipMalloc on the steady-state path; ~100 bytes per
+ * point of the largest call so far).  This frees it -- and the staged block / slab state -- without destroying the
+ * context; the next call allocates again. */
+int vcp_release_workspace(vcp_ctx* ctx);
+
 /* -- per-phase device timing (hipEvents on the launch stream) ----------------------------- */
 /* When enabled, every compute call records hipEvents around each kernel phase on the stream
  * it launches on.  vcp_timing_get returns the phases of the LAST call. */

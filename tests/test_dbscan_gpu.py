@@ -145,3 +145,23 @@ def test_coarsened_grid_and_far_outliers(vcp_ctx, oracle, metric):
     _same(vcp_ctx.dbscan(flat, 0.05, 5, metric), oracle.dbscan(flat, 0.05, 5, metric), "flat axis")
     big = c[:5000] + 1e12                                                         # eps far below one ulp spacing issues
     _same(vcp_ctx.dbscan(big, 0.05, 5, metric), oracle.dbscan(big, 0.05, 5, metric), "offset 1e12")
+
+
+def test_release_workspace_and_reuse(oracle):
+    """vcp_release_workspace frees the device buffers kept between calls; the context keeps working."""
+    import torch
+    ctx = N.Context(0)
+    d = synth.config_cloud(300_000, seed=13)
+    g1 = ctx.dbscan(d["motor"], d["eps_l1"], d["min_pts"])
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    ctx.release_workspace()
+    assert torch.cuda.mem_get_info()[0] > free0
+    ctx.release_workspace()  # idempotent
+    g2 = ctx.dbscan(d["motor"], d["eps_l1"], d["min_pts"])
+    assert np.array_equal(g1["labels"], g2["labels"]) and g1["cf"] == g2["cf"]
+    ctx.blocks_begin(d["motor"], 0.07, 7, 200, 3)
+    ctx.release_workspace()
+    with pytest.raises(N.VcpError):  # the staged block state went with the workspace
+        ctx.blocks_share(0, 1)
+    ctx.close()

@@ -25,7 +25,7 @@ SYMBOLS = [
     "vcp_blocks_share", "vcp_blocks_cluster_dev", "vcp_blocks_finish_dev", "vcp_centroids", "vcp_centroids_dev",
     "vcp_merge_centroids", "vcp_refresh_by_dictionary", "vcp_icp", "vcp_icp_dev", "vcp_icp_sums",
     "vcp_match", "vcp_mcc", "vcp_assign_truths", "vcp_icp_vtklike", "vcp_import_convert",
-    "vcp_slab_begin", "vcp_slab_comps", "vcp_slab_finish",
+    "vcp_slab_begin", "vcp_slab_comps", "vcp_slab_finish", "vcp_release_workspace",
 ]
 
 
@@ -103,6 +103,10 @@ class Context:
     # -- plumbing ------------------------------------------------------------------------------
     def set_stream(self, stream_handle):
         self._chk(lib().vcp_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def release_workspace(self):
+        """Free the device workspace kept between calls (it is re-allocated on demand)."""
+        self._chk(lib().vcp_release_workspace(self._h))
 
     def timing_enable(self, on=True):
         self._chk(lib().vcp_timing_enable(self._h, int(on)))

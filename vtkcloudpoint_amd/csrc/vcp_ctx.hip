@@ -263,6 +263,21 @@ int vcp_create(int device_id, vcp_ctx** out) {
 void vcp_blocks_state_free(vcp_ctx* ctx);  // blocks.hip
 void vcp_slab_state_free(vcp_ctx* ctx);    // dbscan.hip
 
+int vcp_release_workspace(vcp_ctx* ctx) {
+  if (!ctx) return VCP_ERR_ARG;
+  VCP_TRY(vcp_bind(ctx));
+  VCP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  vcp_blocks_state_free(ctx);
+  vcp_slab_state_free(ctx);
+  for (DevBuf* b : ctx->bufs) {
+    if (b->p) (void)hipFree(b->p);
+    b->p = nullptr;
+    b->cap = 0;
+  }
+  ctx->bufs.clear();  // vcp_ensure registers a buffer again when it allocates it
+  return VCP_OK;
+}
+
 void vcp_destroy(vcp_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);

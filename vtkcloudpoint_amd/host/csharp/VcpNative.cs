@@ -17,6 +17,7 @@ namespace vtkPointCloud
         [DllImport(Lib)] public static extern int vcp_create(int device_id, out IntPtr ctx);
         [DllImport(Lib)] public static extern void vcp_destroy(IntPtr ctx);
         [DllImport(Lib)] public static extern IntPtr vcp_last_error(IntPtr ctx);
+        [DllImport(Lib)] public static extern int vcp_release_workspace(IntPtr ctx);
 
         [DllImport(Lib)] public static extern int vcp_dbscan(IntPtr ctx, double[] coords, long n, int dim, int metric,
             double eps, int min_pts, int cf_in, byte[] in_mask, byte[] in_classed, int[] labels, byte[] is_core,

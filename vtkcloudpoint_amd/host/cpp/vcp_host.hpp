@@ -37,6 +37,8 @@ class Context {
   void check(int rc) const {
     if (rc != VCP_OK) throw VcpException(rc, vcp_last_error(ctx_));
   }
+  // give the device workspace back (it is re-allocated by the next call)
+  void release_workspace() { check(vcp_release_workspace(ctx_)); }
 
  private:
   vcp_ctx* ctx_ = nullptr;

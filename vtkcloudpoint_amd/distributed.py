@@ -78,30 +78,63 @@ def allreduce_sum_int(v, device, group=None):
     return int(t.item())
 
 
+def allgather_known(local_full, ranges, extra, group=None, force=False):
+    """The label exchange of sharded_blocks as ONE collective.  local_full: int32 tensor [m]; ranges[r] = the
+    [lo, hi) slice rank r has filled -- every rank derives all of them from the identical partition, so no size
+    exchange (and no host round trip) precedes the data.  `extra` (an int64 per rank, the op counter) rides in two
+    trailing int32 words of each rank's message.  Slices are padded to the largest one (RCCL all-gathers want equal
+    sizes).  Returns (local_full with every slice filled in, sum of all ranks' extra, bytes this rank sent)."""
+    rank, world = _world(group)
+    if world == 1 and not (force and dist.is_available() and dist.is_initialized()):
+        return local_full, int(extra), 0
+    dev = local_full.device
+    width = max(hi - lo for lo, hi in ranges) + 2
+    lo, hi = ranges[rank]
+    send = torch.empty(width, dtype=torch.int32, device=dev)
+    send[: hi - lo] = local_full[lo:hi]
+    send[width - 2:] = torch.tensor([int(extra)], dtype=torch.int64).view(torch.int32).to(dev)
+    recv = torch.empty(world * width, dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    for r in range(world):
+        rlo, rhi = ranges[r]
+        if r != rank and rhi > rlo:
+            local_full[rlo:rhi] = recv[r * width: r * width + (rhi - rlo)]
+    tails = recv.view(world, width)[:, width - 2:].contiguous().cpu()  # the one host read of the step
+    total = int(tails.view(torch.int64).sum().item())
+    return local_full, total, width * 4
+
+
 def sharded_blocks(backend, motor, eps, min_pts, pts_in_cell, small_max=3, group=None, device="cuda",
-                   motor_dev_ptr=None):
+                   motor_dev_ptr=None, local=None, labels=None, force_collective=False):
     """Run the block pipeline with the per-block step sharded over the ranks of `group`.
 
     backend: object with blocks_begin / blocks_share / blocks_cluster_dev / blocks_finish_dev (a
     vtkcloudpoint_amd._native.Context; the CPU tests pass an oracle-backed stand-in with the same methods
-    that works on CPU tensors).  Returns dict(labels [n] int32 tensor, local [m], kept, cluster_amount, ...).
+    that works on CPU tensors).  local [>= m] / labels [>= n]: optional preallocated int32 work / output tensors
+    (a timed loop passes them so that no allocation or fill sits in the step).
+    Returns dict(labels [n] int32 tensor, local [m], kept, cluster_amount, ..., collective_bytes).
     """
     rank, world = _world(group)
-    n = len(motor)
+    n = len(motor) if motor is not None else None
     if motor_dev_ptr is not None:
+        n = int(n if n is not None else 0)
         info = backend.blocks_begin(None, eps, min_pts, pts_in_cell, small_max, device_ptr=motor_dev_ptr, n=n)
     else:
         info = backend.blocks_begin(motor, eps, min_pts, pts_in_cell, small_max)
     m = info["m"]
-    lo, hi, plo, phi = backend.blocks_share(rank, world)
-    local = torch.zeros(max(m, 1), dtype=torch.int32, device=device)
+    shares = [backend.blocks_share(r, world) for r in range(world)]  # same partition, same cuts on every rank
+    lo, hi, plo, phi = shares[rank]
+    if local is None:
+        local = torch.zeros(max(m, 1), dtype=torch.int32, device=device)
     evals = backend.blocks_cluster_dev(lo, hi, local.data_ptr())
-    local = allgather_varlen(local, plo, phi, m, group)
-    evals = allreduce_sum_int(evals, device, group)
-    labels = torch.zeros(max(n, 1), dtype=torch.int32, device=device)
+    # the library call above has returned = its stream is drained; the collective runs on torch's streams and the
+    # host read of the op counters inside allgather_known drains those before CompleteWork3 is launched
+    local, evals, sent = allgather_known(local, [(s[2], s[3]) for s in shares], evals, group, force_collective)
+    if labels is None:
+        labels = torch.zeros(max(n, 1), dtype=torch.int32, device=device)
     out = backend.blocks_finish_dev(local.data_ptr(), evals, labels.data_ptr())
     out.update(labels=labels[:n], local=local[:m], rows=info["rows"], cols=info["cols"], nblocks=info["nblocks"],
-               block_range=(lo, hi))
+               block_range=(lo, hi), m=m, collective_bytes=sent)
     return out
 
 

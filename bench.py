@@ -196,10 +196,10 @@ def cpu_baseline(cloud, coords, eps, min_pts, metric_id, budget_s=7.0):
     }
     if metric_id == 0:
         # B2: block pipeline at the UI defaults.  The literal FindAll partition (Tools.cs:510-513) is O(n * blocks):
-        # sample = the 1 M points nearest to blob 0; per-block DBImproved in its literal form, noise pass in the
+        # sample = the 600 k points nearest to blob 0; per-block DBImproved in its literal form, noise pass in the
         # grid form (its literal O(Z^2) form is what makes the C# pipeline unusable at this size)
         bd = BLOCK_DEFAULTS
-        crop = window(min(n, 1_000_000))
+        crop = window(min(n, 600_000))
         t0 = time.time()
         rb = O.block_pipeline(crop, bd["eps"], bd["min_pts"], bd["pts_in_cell"], bd["small_max"], canonical=True, brute=True)
         t_one = time.time() - t0

@@ -32,12 +32,12 @@
 #include <rocprim/rocprim.hpp>
 
 #include "dbscan_engine.hpp"
+#include "grid_common.hpp"
+
+using namespace vcpg;
 
 namespace {
 
-constexpr int TPB = 256;
-constexpr uint8_t F_CORE = 1, F_CLASSED = 2, F_EXPAND = 4, F_BCAND = 8;
-constexpr uint32_t NONE = 0xFFFFFFFFu;
 // candidates examined per loop trip in the neighbour-search kernels (independent loads in flight per lane)
 #ifndef VCP_UNR2
 #define VCP_UNR2 4
@@ -49,13 +49,6 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 #ifndef VCP_UNRW
 #define VCP_UNRW 4
 #endif
-
-struct GridP {
-  double mn[3];
-  double inv_h;
-  int D[3];         // cells per axis
-  uint32_t ncells;
-};
 
 }  // namespace
 
@@ -72,16 +65,6 @@ struct SlabState {
 
 namespace {
 
-// linear id of cell (cx,cy,cz), x fastest: the 3 cells of a neighbour row are one contiguous position range.
-// (A tile-major order -- tiles of 4..16 cells per axis -- was measured 5-25 % SLOWER on MI355X for these
-// latency-bound search loops, with or without the XCD-aware block map, and was dropped.)
-template <int GD>
-__device__ __forceinline__ uint32_t cell_id(const GridP& g, int cx, int cy, int cz) {
-  uint32_t id = (uint32_t)cy * (uint32_t)g.D[0] + (uint32_t)cx;
-  if (GD == 3) id += (uint32_t)cz * (uint32_t)g.D[0] * (uint32_t)g.D[1];
-  return id;
-}
-
 template <int METRIC>
 __device__ __forceinline__ bool within(const double* a, const double* b, double thr) {
   double dx = a[0] - b[0];
@@ -93,39 +76,6 @@ __device__ __forceinline__ bool within(const double* a, const double* b, double 
   } else {
     double dz = a[2] - b[2];
     return dx * dx + dy * dy + dz * dz <= thr;
-  }
-}
-
-__device__ __forceinline__ int cell_coord(double x, double mn, double inv_h, int D) {
-  double u = (x - mn) * inv_h;
-  if (u >= 0.0 && u < (double)D) return (int)u;
-  if (u >= (double)D) return D - 1;
-  return 0;  // below the minimum or NaN
-}
-
-template <int GD>
-__device__ __forceinline__ void load_pt(const double* __restrict__ c, int64_t i, double* q) {
-  if (GD == 2) {
-    double2 v = *reinterpret_cast<const double2*>(c + 2 * i);
-    q[0] = v.x;
-    q[1] = v.y;
-  } else {
-    q[0] = c[3 * i];
-    q[1] = c[3 * i + 1];
-    q[2] = c[3 * i + 2];
-  }
-}
-
-// caller-order input: `stride` doubles per point, the metric reads the first GD of them
-template <int GD>
-__device__ __forceinline__ void load_in(const double* __restrict__ c, int64_t i, int stride, double* q) {
-  if (GD == 2 && stride == 2) {
-    double2 v = *reinterpret_cast<const double2*>(c + 2 * i);
-    q[0] = v.x;
-    q[1] = v.y;
-  } else {
-#pragma unroll
-    for (int a = 0; a < GD; a++) q[a] = c[i * stride + a];
   }
 }
 
@@ -253,16 +203,6 @@ __global__ __launch_bounds__(TPB) void k_moments(const double* __restrict__ c, i
     for (int k = 1; k < TPB / 64; k++) v += sm[k][threadIdx.x];
     partial[(size_t)blockIdx.x * 9 + threadIdx.x] = v;
   }
-}
-
-// ---- grid build -------------------------------------------------------------------------------
-template <int GD>
-__device__ __forceinline__ uint32_t cell_of(const double* q, const GridP& g, int* cc) {
-  cc[0] = cell_coord(q[0], g.mn[0], g.inv_h, g.D[0]);
-  cc[1] = cell_coord(q[1], g.mn[1], g.inv_h, g.D[1]);
-  cc[2] = 0;
-  if (GD == 3) cc[2] = cell_coord(q[2], g.mn[2], g.inv_h, g.D[2]);
-  return cell_id<GD>(g, cc[0], cc[1], cc[2]);
 }
 
 // ---- sort-based grid build ---------------------------------------------------------------------------
@@ -1498,8 +1438,32 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   unsigned long long* counters = reinterpret_cast<unsigned long long*>(d_bounds + 8);
   uint32_t* d_total = reinterpret_cast<uint32_t*>(counters + 2);
 
-  // 4. cell order: sort (cell id, index) pairs, cell starts from the sorted keys, gather
-  {
+  // 4. cell order.  Two-level partition that carries the coordinates (gridbuild.hip); grids too large for its
+  //    one-level coarse split keep the round-1 build: sort (cell id, index) pairs, cell starts from the sorted keys,
+  //    gather.  The partition's output pass needs no caller-order -> cell-order map (pos).
+  const bool part = vcp_grid_partition_fits(n, g.ncells);
+  const bool part_out = part && !GROUPED && !d_ord && !(ext && ext->slab) && n <= ((int64_t)1 << 27);
+  if (part) {
+    if (!d_in_classed) VCP_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)n, st));
+    GridBuildArgs ga;
+    ga.d_coords = d_coords;
+    ga.n = n;
+    ga.stride = stride;
+    ga.gd = GD;
+    ga.g = g;
+    ga.d_group = d_group;
+    ga.glo = glo;
+    ga.ghi = ghi;
+    ga.d_ord = d_ord;
+    ga.d_in_classed = d_in_classed;
+    ga.cellstart = cellcnt;
+    ga.sorted = sorted;
+    ga.sord = sord;
+    ga.sgroup = sgroup;
+    ga.flags = flags;
+    ga.pos = part_out ? nullptr : pos;
+    VCP_TRY(vcp_grid_build_partition(ctx, ga));
+  } else {
     vcp_phase(ctx, "cell_key");
     VCP_TRY(vcp_ensure(ctx, ctx->b_skey, (size_t)n * 4));
     uint32_t* skey = ctx->b_skey.as<uint32_t>();
@@ -1603,9 +1567,24 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   hipLaunchKernelGGL(k_labk_rest, dim3(nb), dim3(TPB), 0, st, flags, parent, rootk, labk, cellcnt, g.ncells);
   hipLaunchKernelGGL((k_border<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup, flags,
                      parent, sord, rootk, clseed, labk, counters, GROUPED ? ext->d_group_twice : nullptr, wlB, 0u, NONE);
-  vcp_phase(ctx, "output");
-  hipLaunchKernelGGL((k_output<GROUPED>), dim3(nb), dim3(TPB), 0, st, n, pos, labk, d_in_classed, d_group,
-                     GROUPED ? ext->d_groupstart : nullptr, seedflag, seedpref, cf_in, d_labels, d_is_core, d_is_classed, counters);
+  if (part_out) {
+    GridOutputArgs oa;
+    oa.n = n;
+    oa.sord = sord;
+    oa.labk = labk;
+    oa.have_in_classed = d_in_classed != nullptr;
+    oa.cf_in = cf_in;
+    oa.labels = d_labels;
+    oa.is_core = d_is_core;
+    oa.is_classed = d_is_classed;
+    oa.counters = counters;
+    VCP_TRY(vcp_grid_output_partition(ctx, oa));
+  } else {
+    vcp_phase(ctx, "output");
+    hipLaunchKernelGGL((k_output<GROUPED>), dim3(nb), dim3(TPB), 0, st, n, pos, labk, d_in_classed, d_group,
+                       GROUPED ? ext->d_groupstart : nullptr, seedflag, seedpref, cf_in, d_labels, d_is_core, d_is_classed,
+                       counters);
+  }
   if (GROUPED) {
     hipLaunchKernelGGL(k_group_stats, dim3(vcp_blocks(G, TPB)), dim3(TPB), 0, st, G, glo, ghi, ext->d_groupstart,
                        seedflag, seedpref, ext->d_group_twice, ext->d_group_nclus, counters + 3);

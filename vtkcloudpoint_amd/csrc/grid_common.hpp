@@ -1,0 +1,122 @@
+// grid_common.hpp -- what the grid build (gridbuild.hip) and the search kernels (dbscan.hip) share: the grid
+// geometry, cell arithmetic and point loads.  Everything is internal linkage (each translation unit its own copy).
+#pragma once
+#include "vcp_ctx.hpp"
+
+namespace vcpg {
+
+constexpr int TPB = 256;
+constexpr uint8_t F_CORE = 1, F_CLASSED = 2, F_EXPAND = 4, F_BCAND = 8;
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+struct GridP {
+  double mn[3];
+  double inv_h;
+  int D[3];         // cells per axis
+  uint32_t ncells;
+};
+
+// linear id of cell (cx,cy,cz), x fastest: the 3 cells of a neighbour row are one contiguous position range.
+// (A tile-major order -- tiles of 4..16 cells per axis -- was measured 5-25 % SLOWER on MI355X for these
+// latency-bound search loops, with or without the XCD-aware block map, and was dropped.)
+template <int GD>
+__device__ __forceinline__ uint32_t cell_id(const GridP& g, int cx, int cy, int cz) {
+  uint32_t id = (uint32_t)cy * (uint32_t)g.D[0] + (uint32_t)cx;
+  if (GD == 3) id += (uint32_t)cz * (uint32_t)g.D[0] * (uint32_t)g.D[1];
+  return id;
+}
+
+__device__ __forceinline__ int cell_coord(double x, double mn, double inv_h, int D) {
+  double u = (x - mn) * inv_h;
+  if (u >= 0.0 && u < (double)D) return (int)u;
+  if (u >= (double)D) return D - 1;
+  return 0;  // below the minimum or NaN
+}
+
+template <int GD>
+__device__ __forceinline__ void load_pt(const double* __restrict__ c, int64_t i, double* q) {
+  if (GD == 2) {
+    double2 v = *reinterpret_cast<const double2*>(c + 2 * i);
+    q[0] = v.x;
+    q[1] = v.y;
+  } else {
+    q[0] = c[3 * i];
+    q[1] = c[3 * i + 1];
+    q[2] = c[3 * i + 2];
+  }
+}
+
+template <int GD>
+__device__ __forceinline__ void store_pt(double* __restrict__ c, int64_t i, const double* q) {
+  if (GD == 2) {
+    *reinterpret_cast<double2*>(c + 2 * i) = make_double2(q[0], q[1]);
+  } else {
+    c[3 * i] = q[0];
+    c[3 * i + 1] = q[1];
+    c[3 * i + 2] = q[2];
+  }
+}
+
+// caller-order input: `stride` doubles per point, the metric reads the first GD of them
+template <int GD>
+__device__ __forceinline__ void load_in(const double* __restrict__ c, int64_t i, int stride, double* q) {
+  if (GD == 2 && stride == 2) {
+    double2 v = *reinterpret_cast<const double2*>(c + 2 * i);
+    q[0] = v.x;
+    q[1] = v.y;
+  } else {
+#pragma unroll
+    for (int a = 0; a < GD; a++) q[a] = c[i * stride + a];
+  }
+}
+
+template <int GD>
+__device__ __forceinline__ uint32_t cell_of(const double* q, const GridP& g, int* cc) {
+  cc[0] = cell_coord(q[0], g.mn[0], g.inv_h, g.D[0]);
+  cc[1] = cell_coord(q[1], g.mn[1], g.inv_h, g.D[1]);
+  cc[2] = 0;
+  if (GD == 3) cc[2] = cell_coord(q[2], g.mn[2], g.inv_h, g.D[2]);
+  return cell_id<GD>(g, cc[0], cc[1], cc[2]);
+}
+
+}  // namespace vcpg
+
+// ---- grid build by two-level partition (gridbuild.hip) ------------------------------------------------------
+// Caller order -> cell order without a (key, index) sort and without a per-point random gather: the coordinates travel
+// with the index through one coarse partition (buckets = contiguous ranges of cell ids) and one per-bucket counting
+// sort in LDS that also emits the bucket's slice of the cell table.
+struct GridBuildArgs {
+  const double* d_coords = nullptr;  // [n * stride] caller order
+  int64_t n = 0;
+  int stride = 2, gd = 2;
+  vcpg::GridP g;
+  const int32_t* d_group = nullptr;  // grouped calls: points with group outside [glo, ghi) are left out
+  int glo = 0, ghi = 0;
+  const uint32_t* d_ord = nullptr;          // list position of point i (NULL = i)
+  const uint8_t* d_in_classed = nullptr;    // NULL = flags are zero-filled by the caller
+  // outputs (cell order unless noted)
+  uint32_t* cellstart = nullptr;  // [ncells + 1]
+  double* sorted = nullptr;       // [nin * gd]
+  uint32_t* sord = nullptr;       // [nin]
+  int32_t* sgroup = nullptr;      // [nin], grouped only
+  uint8_t* flags = nullptr;       // [nin], written only with d_in_classed
+  uint32_t* pos = nullptr;        // [n] caller order, NONE for left-out points; NULL = not wanted
+};
+// false when the grid is too large for the one-level coarse partition (the caller keeps the sort-based build)
+bool vcp_grid_partition_fits(int64_t n, uint32_t ncells);
+int vcp_grid_build_partition(vcp_ctx* ctx, const GridBuildArgs& a);
+
+// Cell order -> caller order the same way (no per-point random gather): (list position, label word) pairs are
+// partitioned by windows of 2^13 list positions, then every window is assembled in LDS and stored as full lines.
+struct GridOutputArgs {
+  int64_t n = 0;
+  const uint32_t* sord = nullptr;  // [n] list position of cell-order position p (a permutation of [0, n))
+  const uint32_t* labk = nullptr;  // [n] (1 + seed rank) << 2 | core | classed << 1
+  bool have_in_classed = false;
+  int32_t cf_in = 0;
+  int32_t* labels = nullptr;
+  uint8_t* is_core = nullptr;
+  uint8_t* is_classed = nullptr;
+  unsigned long long* counters = nullptr;  // [4..36): points not classed on entry (only with have_in_classed)
+};
+int vcp_grid_output_partition(vcp_ctx* ctx, const GridOutputArgs& a);

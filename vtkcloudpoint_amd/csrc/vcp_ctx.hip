@@ -30,8 +30,10 @@ int vcp_ensure(vcp_ctx* ctx, DevBuf& b, size_t bytes) {
     VCP_HIP(ctx, hipFree(b.p));
     b.p = nullptr;
     b.cap = 0;
-  } else {
+  }
+  if (!b.registered) {  // a buffer whose regrow failed (p == nullptr again) must not be listed twice
     ctx->bufs.push_back(&b);
+    b.registered = true;
   }
   size_t want = bytes + bytes / 8 + 256;  // headroom so that slowly growing inputs do not realloc
   hipError_t e = hipMalloc(&b.p, want);
@@ -273,6 +275,7 @@ int vcp_release_workspace(vcp_ctx* ctx) {
     if (b->p) (void)hipFree(b->p);
     b->p = nullptr;
     b->cap = 0;
+    b->registered = false;
   }
   ctx->bufs.clear();  // vcp_ensure registers a buffer again when it allocates it
   return VCP_OK;
@@ -284,8 +287,10 @@ void vcp_destroy(vcp_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   vcp_blocks_state_free(ctx);
   vcp_slab_state_free(ctx);
-  for (DevBuf* b : ctx->bufs)
+  for (DevBuf* b : ctx->bufs) {
     if (b->p) (void)hipFree(b->p);
+    b->p = nullptr;
+  }
   for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

@@ -123,6 +123,15 @@ int vcp_dbscan_blocks(vcp_ctx* ctx, const double* motor, int64_t n, double eps, 
                       int64_t* merge_order, int64_t* m_out, int32_t* rows, int32_t* cols,
                       int32_t* kept, int32_t* del_sum, int32_t* cluster_amount, int64_t* dist_evals);
 
+/* The 3-D twin MainForm.getClusterFromList (FrmMain.cs:1136-1213 with Tools.getListByScale, BC/Tools.cs:507-509): the
+ * same pipeline, but the PARTITION (bounds, sort key, first-block size, (lo,hi] rectangles) reads key_xy [n*2] = (X, Y)
+ * while every DBImproved -- per block and the noise pass -- still clusters on motor [n*2] (StartCode :2785-2786).
+ * key_xy == NULL is vcp_dbscan_blocks. */
+int vcp_dbscan_blocks_keyed(vcp_ctx* ctx, const double* key_xy, const double* motor, int64_t n, double eps,
+                            int min_pts, int pts_in_cell, int small_max, int32_t* labels, int32_t* block_of,
+                            int64_t* merge_order, int64_t* m_out, int32_t* rows, int32_t* cols, int32_t* kept,
+                            int32_t* del_sum, int32_t* cluster_amount, int64_t* dist_evals);
+
 /* The same pipeline in three stages, for sharding the per-block step over several GPUs (one
  * process and one context per GPU, every rank holds the whole cloud; SURVEY.md 8e mode 1):
  *   begin    partition (deterministic, identical on every rank); *m = points that fell in a block
@@ -139,6 +148,13 @@ int vcp_blocks_begin(vcp_ctx* ctx, const double* motor, int64_t n, double eps, i
 int vcp_blocks_begin_dev(vcp_ctx* ctx, const double* d_motor, int64_t n, double eps, int min_pts,
                          int pts_in_cell, int small_max, int32_t* rows, int32_t* cols,
                          int64_t* nblocks, int64_t* m);
+/* begin with separate partition keys (getClusterFromList); share / cluster / finish are unchanged */
+int vcp_blocks_begin_keyed(vcp_ctx* ctx, const double* key_xy, const double* motor, int64_t n, double eps,
+                           int min_pts, int pts_in_cell, int small_max, int32_t* rows, int32_t* cols,
+                           int64_t* nblocks, int64_t* m);
+int vcp_blocks_begin_keyed_dev(vcp_ctx* ctx, const double* d_key_xy, const double* d_motor, int64_t n, double eps,
+                               int min_pts, int pts_in_cell, int small_max, int32_t* rows, int32_t* cols,
+                               int64_t* nblocks, int64_t* m);
 int vcp_blocks_share(vcp_ctx* ctx, int rank, int world, int32_t* block_lo, int32_t* block_hi,
                      int64_t* pos_lo, int64_t* pos_hi);
 int vcp_blocks_cluster_dev(vcp_ctx* ctx, int32_t block_lo, int32_t block_hi, int32_t* d_local,
@@ -187,6 +203,17 @@ int vcp_centroids(vcp_ctx* ctx, const double* xyz, const double* motor, const in
                   int64_t n, int32_t K, double* c3, double* c2, int64_t* counts);
 int vcp_centroids_dev(vcp_ctx* ctx, const double* d_xyz, const double* d_motor, const int32_t* d_labels,
                       int64_t n, int32_t K, double* d_c3, double* d_c2, int64_t* d_counts);
+
+/* Replaces Tools.getFixedPtsCentroid(clusList, isIgnoreDuplication) (BC/Tools.cs:78-111; caller
+ * SureDistanceFilter.cs:74): per list 1..K the ptsCount-weighted mean of (X,Y,Z).  group [n] = which ClusObj.li the
+ * point sits in (1..K, 0 = none); cluster_id [n] = Point3D.clusterId (NULL = group); pts_count [n] = Point3D.ptsCount
+ * (FrmMain.cs:1074,1081: multiplicity of a deduplicated fixed point).  A member with clusterId != 0 counts ONCE when
+ * ignore_duplication is set, otherwise ptsCount times (:88-101).  c3 [K*3]; inside_num [K] (may be NULL) = the C#'s
+ * insideNum (0 gives NaN rows, 0/0).  An empty list makes the C# throw at li[0] (:106): VCP_ERR_INDEX.
+ * Sums are the fixed tree of vcp_centroids (1e-12 relative to the C#'s sequential sum). */
+int vcp_centroids_weighted(vcp_ctx* ctx, const double* xyz, const int32_t* group, const int32_t* cluster_id,
+                           const int32_t* pts_count, int64_t n, int32_t K, int ignore_duplication, double* c3,
+                           int64_t* inside_num);
 
 /* Replaces Tools.MergeIDByDistance (BC/Tools.cs:580-621): DBImproved(minPts 2, L1 on X,Y) over the
  * K centroids; map_to[k] = cluster id the k-th centroid's cluster is merged into, 0 = none. */

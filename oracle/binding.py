@@ -98,8 +98,10 @@ def db_literal(coords, eps, min_pts, shown=None, classed=None, labels=None, is_k
                 points_amount=pa.value, evals=ev.value)
 
 
-def block_pipeline(motor, eps, min_pts, pts_in_cell, small_max=3, canonical=True, brute=False):
+def block_pipeline(motor, eps, min_pts, pts_in_cell, small_max=3, canonical=True, brute=False, key_xy=None):
+    """key_xy: the partition's coordinates (getClusterFromList reads X,Y); None = motor (getClusterFromMotor)."""
     motor = _f64(motor, 2)
+    key_xy = motor if key_xy is None else _f64(key_xy, 2)
     n = motor.shape[0]
     labels = np.zeros(n, np.int32)
     block_of = np.zeros(n, np.int32)
@@ -107,7 +109,7 @@ def block_pipeline(motor, eps, min_pts, pts_in_cell, small_max=3, canonical=True
     m = C.c_int64(0)
     rows, cols, kept, dels, ca = (C.c_int32(0) for _ in range(5))
     ev = C.c_int64(0)
-    _chk(lib().orc_block_pipeline(_p(motor, C.c_double), C.c_int64(n), C.c_double(eps), int(min_pts),
+    _chk(lib().orc_block_pipeline_keyed(_p(key_xy, C.c_double), _p(motor, C.c_double), C.c_int64(n), C.c_double(eps), int(min_pts),
                                   int(pts_in_cell), int(small_max), int(canonical), int(brute),
                                   _p(labels, C.c_int32), _p(block_of, C.c_int32), _p(order, C.c_int64),
                                   C.byref(m), C.byref(rows), C.byref(cols), C.byref(kept),
@@ -130,6 +132,20 @@ def centroids(xyz, motor, labels, K, order=None):
                              _p(order, C.c_int64), C.c_int64(m), C.c_int32(K), _p(c3, C.c_double),
                              _p(c2, C.c_double), _p(counts, C.c_int64)))
     return c3, c2, counts
+
+
+def fixed_centroids(xyz, group, cluster_id, pts_count, K, ignore_dup):
+    """Tools.getFixedPtsCentroid: returns (c3 [K,3], inside_num [K])."""
+    xyz = _f64(xyz, 3)
+    group = np.ascontiguousarray(group, np.int32)
+    cluster_id = None if cluster_id is None else np.ascontiguousarray(cluster_id, np.int32)
+    pts_count = np.ascontiguousarray(pts_count, np.int32)
+    c3 = np.zeros((K, 3))
+    inside = np.zeros(K, np.int64)
+    _chk(lib().orc_fixed_centroids(_p(xyz, C.c_double), _p(group, C.c_int32), _p(cluster_id, C.c_int32),
+                                   _p(pts_count, C.c_int32), C.c_int64(len(group)), C.c_int32(K), int(bool(ignore_dup)),
+                                   _p(c3, C.c_double), _p(inside, C.c_int64)))
+    return c3, inside
 
 
 def merge_ids(cxy, ids, thr):

@@ -787,11 +787,23 @@ int orc_block_pipeline(const double* motor, int64_t n, double eps, int min_pts, 
                        int32_t* block_of, int64_t* merge_order, int64_t* m_out, int32_t* rows_o,
                        int32_t* cols_o, int32_t* kept_o, int32_t* del_sum_o,
                        int32_t* cluster_amount_o, int64_t* dist_evals_o) {
+  return orc_block_pipeline_keyed(motor, motor, n, eps, min_pts, pts_in_cell, small_max, use_canonical, brute_partition,
+                                  labels, block_of, merge_order, m_out, rows_o, cols_o, kept_o, del_sum_o,
+                                  cluster_amount_o, dist_evals_o);
+}
+
+// getClusterFromList (FrmMain.cs:1136-1213): the partition reads `key` = (X, Y) (Tools.getListByScale, BC/Tools.cs:507-509),
+// StartCode and CompleteWork3 cluster on motor exactly as in getClusterFromMotor.
+int orc_block_pipeline_keyed(const double* key, const double* motor, int64_t n, double eps, int min_pts, int pts_in_cell,
+                             int small_max, int use_canonical, int brute_partition, int32_t* labels,
+                             int32_t* block_of, int64_t* merge_order, int64_t* m_out, int32_t* rows_o,
+                             int32_t* cols_o, int32_t* kept_o, int32_t* del_sum_o,
+                             int32_t* cluster_amount_o, int64_t* dist_evals_o) {
   int32_t rows = 0, cols = 0;
   int64_t m = 0;
   std::vector<int64_t> bl(n > 0 ? n : 1);
   // two calls: the first sizes rows*cols, the second fills blockstart
-  int rc = orc_block_partition(motor, n, pts_in_cell, brute_partition, block_of, nullptr, bl.data(), nullptr, 0, &rows,
+  int rc = orc_block_partition(key, n, pts_in_cell, brute_partition, block_of, nullptr, bl.data(), nullptr, 0, &rows,
                                &cols, &m);
   if (rc) return rc;
   int64_t nblocks = (int64_t)rows * cols;
@@ -836,6 +848,43 @@ int orc_centroids(const double* xyz, const double* motor, const int32_t* labels,
       for (int a = 0; a < 3; a++) c3[3 * k + a] = average(xyz, 3, a, li[k]);  // :192
     if (c2 && motor)
       for (int a = 0; a < 2; a++) c2[2 * k + a] = average(motor, 2, a, li[k]);  // :193
+  }
+  return ORC_OK;
+}
+
+// Tools.getFixedPtsCentroid (BC/Tools.cs:78-111), statement by statement: sequential sums in list order.
+int orc_fixed_centroids(const double* xyz, const int32_t* group, const int32_t* cluster_id, const int32_t* pts_count,
+                        int64_t n, int32_t K, int ignore_dup, double* c3, int64_t* inside_num) {
+  if (n < 0 || K < 0) return ORC_ERR_ARG;
+  std::vector<std::vector<int64_t>> li(K);
+  for (int64_t i = 0; i < n; i++) {
+    const int32_t g = group[i];
+    if (g == 0) continue;
+    if (g < 1 || g > K) return ORC_ERR_INDEX;
+    li[g - 1].push_back(i);
+  }
+  for (int32_t k = 0; k < K; k++) {
+    double X = 0, Y = 0, Z = 0;  // new Point3D(): :82
+    int64_t insideNum = 0;       // int in the C#
+    for (int64_t i : li[k]) {
+      const int32_t cid = cluster_id ? cluster_id[i] : group[i];
+      if (cid != 0 && ignore_dup) {  // :86-92
+        X += xyz[3 * i];
+        Y += xyz[3 * i + 1];
+        Z += xyz[3 * i + 2];
+        insideNum++;
+      } else {  // :95-100
+        X += xyz[3 * i] * pts_count[i];
+        Y += xyz[3 * i + 1] * pts_count[i];
+        Z += xyz[3 * i + 2] * pts_count[i];
+        insideNum += pts_count[i];
+      }
+    }
+    c3[3 * k] = X / (double)insideNum;  // :102-104 (double / int)
+    c3[3 * k + 1] = Y / (double)insideNum;
+    c3[3 * k + 2] = Z / (double)insideNum;
+    if (inside_num) inside_num[k] = insideNum;
+    if (li[k].empty()) return ORC_ERR_INDEX;  // :105 clusList[i].li[0] throws ArgumentOutOfRangeException
   }
   return ORC_OK;
 }

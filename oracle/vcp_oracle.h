@@ -92,6 +92,12 @@ int orc_block_pipeline(const double* motor, int64_t n, double eps, int min_pts, 
                        int32_t* cols, int32_t* kept, int32_t* del_sum, int32_t* cluster_amount,
                        int64_t* dist_evals);
 
+int orc_block_pipeline_keyed(const double* key, const double* motor, int64_t n, double eps, int min_pts, int pts_in_cell,
+                             int small_max, int use_canonical, int brute_partition, int32_t* labels,
+                             int32_t* block_of, int64_t* merge_order, int64_t* m_out, int32_t* rows,
+                             int32_t* cols, int32_t* kept, int32_t* del_sum, int32_t* cluster_amount,
+                             int64_t* dist_evals);
+
 /* The same pipeline in stages (used to check the staged multi-GPU path stage by stage):
  * partition  -> block_of [n], raw [n] (list order after the sort), bl [m] (block-major list of original
  *               indices), blockstart [rows*cols+1] (capacity blockstart_cap entries)
@@ -114,6 +120,10 @@ int orc_block_finish(const double* motor, int64_t n, const int64_t* bl, const in
 int orc_centroids(const double* xyz, const double* motor, const int32_t* labels,
                   const int64_t* order, int64_t m, int32_t K, double* c3, double* c2,
                   int64_t* counts);
+
+/* Tools.getFixedPtsCentroid (BC/Tools.cs:78-111): ptsCount-weighted mean per list; see include/vcp.h. */
+int orc_fixed_centroids(const double* xyz, const int32_t* group, const int32_t* cluster_id, const int32_t* pts_count,
+                        int64_t n, int32_t K, int ignore_dup, double* c3, int64_t* inside_num);
 
 /* Tools.MergeIDByDistance (BC/Tools.cs:580-621): DBImproved(minPts=2, L1 on X,Y) over
  * the K centroids; map_to[k] = id the k-th centroid's cluster is merged into, or 0. */

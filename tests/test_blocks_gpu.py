@@ -92,3 +92,38 @@ def test_errors(vcp_ctx):
     with pytest.raises(N.VcpError) as e:
         vcp_ctx.dbscan_blocks(np.ones((10, 2)), 0.1, 3, 5)
     assert e.value.code == -3  # zero-extent first block
+
+
+def test_keyed_partition_getClusterFromList(vcp_ctx, oracle):
+    """The 3-D twin (FrmMain.cs:1136-1213, Tools.getListByScale BC/Tools.cs:507-509): blocks are cut on (X, Y), every
+    DBImproved still clusters on (motor_x, motor_y).  One-shot and staged forms vs the oracle."""
+    import torch
+    rng = np.random.default_rng(3)
+    for trial in range(60):
+        n = int(rng.integers(20, 500))
+        motor = rng.integers(0, 40, size=(n, 2)).astype(np.float64) * 0.25
+        key = rng.random((n, 2)) * 7 if trial % 2 else rng.integers(0, 30, size=(n, 2)).astype(np.float64) * 0.5
+        eps, mp, pic = 0.5, int(rng.integers(1, 5)), int(rng.integers(3, 40))
+        try:
+            o = oracle.block_pipeline(motor, eps, mp, pic, 3, key_xy=key)
+        except oracle.OracleError as e:
+            with pytest.raises(N.VcpError) as ge:
+                vcp_ctx.dbscan_blocks(motor, eps, mp, pic, 3, key_xy=key)
+            assert ge.value.code == e.code
+            continue
+        _same(vcp_ctx.dbscan_blocks(motor, eps, mp, pic, 3, key_xy=key), o, "keyed trial %d" % trial)
+    d = synth.config_cloud(300_000, seed=12)
+    key = np.ascontiguousarray(d["xyz"][:, :2])
+    o = oracle.block_pipeline(d["motor"], 0.07, 7, 200, 3, key_xy=key)
+    g = vcp_ctx.dbscan_blocks(d["motor"], 0.07, 7, 200, 3, key_xy=key)
+    _same(g, o, "keyed 300k")
+    assert not np.array_equal(g["block_of"], vcp_ctx.dbscan_blocks(d["motor"], 0.07, 7, 200, 3)["block_of"])
+    # staged, device-resident
+    dm, dk = torch.from_numpy(d["motor"]).cuda(), torch.from_numpy(key).cuda()
+    info = vcp_ctx.blocks_begin(None, 0.07, 7, 200, 3, device_ptr=dm.data_ptr(), n=len(key), key_device_ptr=dk.data_ptr())
+    local = torch.zeros(max(info["m"], 1), dtype=torch.int32, device="cuda")
+    lab = torch.zeros(len(key), dtype=torch.int32, device="cuda")
+    ev = vcp_ctx.blocks_cluster_dev(0, info["nblocks"], local.data_ptr())
+    fin = vcp_ctx.blocks_finish_dev(local.data_ptr(), ev, lab.data_ptr())
+    assert np.array_equal(lab.cpu().numpy(), o["labels"]) and fin["cluster_amount"] == o["cluster_amount"]
+    assert fin["evals"] == o["evals"]

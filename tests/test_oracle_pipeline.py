@@ -152,3 +152,42 @@ def test_minimal_bounding_circle_oracle(oracle):
     # Tools.getCircles skips clusters of <= 3 points
     g = oracle.get_circles(np.zeros((3, 2)), np.array([1, 1, 1], np.int32), 1)
     assert g["valid"].tolist() == [0]
+
+
+def test_keyed_partition_and_fixed_centroids(oracle):
+    """getClusterFromList (partition on X,Y; FrmMain.cs:1136-1213): with key == motor it IS getClusterFromMotor; with a
+    different key the literal FindAll sweep and the fast partition still agree.  getFixedPtsCentroid (Tools.cs:78-111)
+    against a direct numpy restatement."""
+    rng = np.random.default_rng(8)
+    for trial in range(40):
+        n = int(rng.integers(20, 300))
+        motor = rng.integers(0, 40, size=(n, 2)).astype(np.float64) * 0.25
+        key = rng.random((n, 2)) * 5
+        pic = int(rng.integers(3, 30))
+        try:
+            a = oracle.block_pipeline(motor, 0.5, 3, pic, 3, key_xy=motor)
+        except oracle.OracleError:
+            continue
+        b = oracle.block_pipeline(motor, 0.5, 3, pic, 3)
+        assert np.array_equal(a["labels"], b["labels"]) and a["evals"] == b["evals"]
+        try:
+            c = oracle.block_pipeline(motor, 0.5, 3, pic, 3, key_xy=key, canonical=False, brute=True)
+        except oracle.OracleError:
+            continue
+        d = oracle.block_pipeline(motor, 0.5, 3, pic, 3, key_xy=key)
+        for k in ("labels", "block_of", "order"):
+            assert np.array_equal(c[k], d[k]), k
+        assert c["evals"] == d["evals"] and c["cluster_amount"] == d["cluster_amount"]
+    n, K = 500, 6
+    xyz = rng.random((n, 3))
+    group = rng.integers(0, K + 1, n).astype(np.int32)
+    group[:K] = np.arange(1, K + 1)
+    pts = rng.integers(1, 5, n).astype(np.int32)
+    cid = np.where(rng.random(n) < 0.3, 0, group).astype(np.int32)
+    for ignore in (False, True):
+        c3, inside = oracle.fixed_centroids(xyz, group, cid, pts, K, ignore)
+        for k in range(K):
+            sel = group == k + 1
+            w = np.where((cid[sel] != 0) & ignore, 1, pts[sel]).astype(np.float64)
+            assert inside[k] == int(w.sum())
+            assert np.allclose(c3[k], (xyz[sel] * w[:, None]).sum(0) / w.sum(), rtol=1e-13)

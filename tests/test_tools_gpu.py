@@ -181,3 +181,36 @@ def test_import_conversion_and_duplicate_removal(vcp_ctx, oracle):
     with pytest.raises(N.VcpError) as e:
         vcp_ctx.import_convert(rows[:10], 0.0, 0.0, 4, 3, True)
     assert e.value.code == -8
+
+
+def test_fixed_points_centroid_weighted(vcp_ctx, oracle):
+    """Tools.getFixedPtsCentroid (BC/Tools.cs:78-111; SureDistanceFilter.cs:74): ptsCount-weighted centroids of the
+    deduplicated fixed points, with and without isIgnoreDuplication, vs the statement-by-statement oracle."""
+    rng = np.random.default_rng(11)
+    n, K = 60_000, 37
+    xyz = rng.random((n, 3)) * 50
+    group = rng.integers(0, K + 1, n).astype(np.int32)  # 0 = in no list
+    group[:K] = np.arange(1, K + 1)  # no list is empty
+    pts = rng.integers(1, 9, n).astype(np.int32)
+    cid = np.where(rng.random(n) < 0.2, 0, group).astype(np.int32)  # some members carry clusterId 0
+    for ignore in (False, True):
+        for c in (cid, None):
+            g3, gi = vcp_ctx.centroids_weighted(xyz, group, c, pts, K, ignore)
+            o3, oi = oracle.fixed_centroids(xyz, group, c, pts, K, ignore)
+            assert np.array_equal(gi, oi)
+            assert np.allclose(g3, o3, rtol=RTOL, atol=1e-12)
+    # unweighted limit: ptsCount 1 everywhere equals Tools.GetClusList's mean
+    ones = np.ones(n, np.int32)
+    g3, gi = vcp_ctx.centroids_weighted(xyz, group, None, ones, K, False)
+    c3, _, cnt = vcp_ctx.centroids(xyz, None, group, K)
+    assert np.array_equal(gi, cnt) and np.allclose(g3, c3, rtol=RTOL)
+    # insideNum == 0 (all weights zero): 0/0 = NaN rows, like the C#
+    z3, zi = vcp_ctx.centroids_weighted(xyz, group, None, np.zeros(n, np.int32), K, False)
+    assert np.isnan(z3).all() and not zi.any()
+    # an empty list: clusList[i].li[0] throws (Tools.cs:106)
+    group[group == 5] = 0
+    with pytest.raises(N.VcpError) as e:
+        vcp_ctx.centroids_weighted(xyz, group, None, pts, K, False)
+    assert e.value.code == -4
+    with pytest.raises(oracle.OracleError):
+        oracle.fixed_centroids(xyz, group, None, pts, K, False)

@@ -26,6 +26,7 @@ SYMBOLS = [
     "vcp_merge_centroids", "vcp_refresh_by_dictionary", "vcp_icp", "vcp_icp_dev", "vcp_icp_sums",
     "vcp_match", "vcp_mcc", "vcp_assign_truths", "vcp_icp_vtklike", "vcp_import_convert",
     "vcp_slab_begin", "vcp_slab_comps", "vcp_slab_finish", "vcp_release_workspace",
+    "vcp_centroids_weighted", "vcp_dbscan_blocks_keyed", "vcp_blocks_begin_keyed", "vcp_blocks_begin_keyed_dev",
 ]
 
 
@@ -201,6 +202,19 @@ class Context:
                                       C.c_int32(K), _ptr(c3), _ptr(c2), _ptr(counts)))
         return c3, c2, counts
 
+    def centroids_weighted(self, xyz, group, cluster_id, pts_count, K, ignore_duplication):
+        """Tools.getFixedPtsCentroid: returns (c3 [K,3], inside_num [K])."""
+        xyz = _f64(xyz, 3)
+        group = np.ascontiguousarray(group, np.int32)
+        cluster_id = None if cluster_id is None else np.ascontiguousarray(cluster_id, np.int32)
+        pts_count = np.ascontiguousarray(pts_count, np.int32)
+        c3 = np.zeros((K, 3))
+        inside = np.zeros(K, np.int64)
+        self._chk(lib().vcp_centroids_weighted(self._h, _ptr(xyz), _ptr(group), _ptr(cluster_id), _ptr(pts_count),
+                                               C.c_int64(len(group)), C.c_int32(K), int(bool(ignore_duplication)),
+                                               _ptr(c3), _ptr(inside)))
+        return c3, inside
+
     def centroids_dev(self, d_xyz, d_motor, d_labels, n, K, d_c3, d_c2, d_counts):
         """Device-pointer form of centroids (any of d_xyz / d_motor and its output may be None)."""
         self._chk(lib().vcp_centroids_dev(self._h, _ptr(d_xyz), _ptr(d_motor), _ptr(d_labels), C.c_int64(n),
@@ -247,28 +261,42 @@ class Context:
         return dict(matched_xyz=mxyz, is_matched=is_m, nearest=nearest, nearest_dist=nd, count=cnt.value)
 
     # -- block-partitioned pipeline ------------------------------------------------------------------
-    def dbscan_blocks(self, motor, eps, min_pts, pts_in_cell, small_max=3):
-        """MainForm.getClusterFromMotor + StartCode + CompleteWork3 in one call (host buffers)."""
+    def dbscan_blocks(self, motor, eps, min_pts, pts_in_cell, small_max=3, key_xy=None):
+        """MainForm.getClusterFromMotor + StartCode + CompleteWork3 in one call (host buffers).  key_xy: the (X, Y)
+        the partition of the twin getClusterFromList reads (FrmMain.cs:1136-1213); None = the motor coordinates."""
         motor = _f64(motor, 2)
         n = len(motor)
+        key_xy = None if key_xy is None else _f64(key_xy, 2)
         labels = np.zeros(n, np.int32)
         block_of = np.zeros(n, np.int32)
         order = np.zeros(max(n, 1), np.int64)
         m = C.c_int64(0)
         rows, cols, kept, dels, ca = (C.c_int32(0) for _ in range(5))
         ev = C.c_int64(0)
-        self._chk(lib().vcp_dbscan_blocks(self._h, _ptr(motor), C.c_int64(n), C.c_double(eps), int(min_pts),
-                                          int(pts_in_cell), int(small_max), _ptr(labels), _ptr(block_of),
-                                          _ptr(order), C.byref(m), C.byref(rows), C.byref(cols), C.byref(kept),
-                                          C.byref(dels), C.byref(ca), C.byref(ev)))
+        self._chk(lib().vcp_dbscan_blocks_keyed(self._h, _ptr(key_xy), _ptr(motor), C.c_int64(n), C.c_double(eps),
+                                                int(min_pts), int(pts_in_cell), int(small_max), _ptr(labels),
+                                                _ptr(block_of), _ptr(order), C.byref(m), C.byref(rows), C.byref(cols),
+                                                C.byref(kept), C.byref(dels), C.byref(ca), C.byref(ev)))
         return dict(labels=labels, block_of=block_of, order=order[: m.value].copy(), rows=rows.value,
                     cols=cols.value, kept=kept.value, del_sum=dels.value, cluster_amount=ca.value,
                     evals=ev.value)
 
-    def blocks_begin(self, motor, eps, min_pts, pts_in_cell, small_max=3, device_ptr=None, n=None):
+    def blocks_begin(self, motor, eps, min_pts, pts_in_cell, small_max=3, device_ptr=None, n=None, key_xy=None,
+                     key_device_ptr=None):
         rows, cols = C.c_int32(0), C.c_int32(0)
         nb, m = C.c_int64(0), C.c_int64(0)
-        if device_ptr is None:
+        if key_xy is not None or key_device_ptr is not None:  # getClusterFromList: partition on (X, Y)
+            if device_ptr is None:
+                motor, key_xy = _f64(motor, 2), _f64(key_xy, 2)
+                self._chk(lib().vcp_blocks_begin_keyed(self._h, _ptr(key_xy), _ptr(motor), C.c_int64(len(motor)),
+                                                       C.c_double(eps), int(min_pts), int(pts_in_cell), int(small_max),
+                                                       C.byref(rows), C.byref(cols), C.byref(nb), C.byref(m)))
+            else:
+                self._chk(lib().vcp_blocks_begin_keyed_dev(self._h, _ptr(key_device_ptr), _ptr(device_ptr), C.c_int64(n),
+                                                           C.c_double(eps), int(min_pts), int(pts_in_cell),
+                                                           int(small_max), C.byref(rows), C.byref(cols), C.byref(nb),
+                                                           C.byref(m)))
+        elif device_ptr is None:
             motor = _f64(motor, 2)
             self._chk(lib().vcp_blocks_begin(self._h, _ptr(motor), C.c_int64(len(motor)), C.c_double(eps),
                                              int(min_pts), int(pts_in_cell), int(small_max), C.byref(rows),

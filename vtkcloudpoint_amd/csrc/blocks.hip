@@ -30,7 +30,7 @@ struct BlocksState {
   double eps = 0;
   int min_pts = 0, small_max = 3, take = 0;
   double x_Min = 0, x_Max = 0, y_Min = 0, y_Max = 0, cell_x = 0, cell_y = 0;
-  DevBuf motor, raw, rankpos, blockof, bl, motor_bm, blockstart, gtwice, gnclus, tmp0, tmp1, tmp2, tmp3, sorttmp,
+  DevBuf motor, pkey, raw, rankpos, blockof, bl, motor_bm, blockstart, gtwice, gnclus, tmp0, tmp1, tmp2, tmp3, sorttmp,
       blk_t, csize, cstart, kb, zb, keep, order, newlab, zflag, zlist, zcoords, zlab, misc;
   std::vector<uint32_t> h_blockstart;
   bool ready = false;
@@ -433,8 +433,13 @@ __global__ __launch_bounds__(BT) void k_scatter_zlab(const int32_t* __restrict__
 
 unsigned nblk(int64_t n) { return vcp_blocks(n, BT); }
 
-int blocks_begin(vcp_ctx* ctx, const double* d_motor_in, bool from_host, const double* h_motor, int64_t n, double eps,
-                 int min_pts, int pts_in_cell, int small_max, int32_t* rows_o, int32_t* cols_o, int64_t* m_o) {
+// key_in: the coordinates the PARTITION reads -- (motor_x, motor_y) in getClusterFromMotor (FrmMain.cs:1214-1291,
+// Tools.getListByScale2), (X, Y) in its twin getClusterFromList (:1136-1213, Tools.getListByScale :507-509); the
+// per-block DBImproved and the noise pass always cluster on motor (StartCode :2785-2786, BC/DBImproved.cs:16-21).
+// NULL = the motor coordinates themselves.
+int blocks_begin(vcp_ctx* ctx, const double* d_motor_in, bool from_host, const double* h_motor, const double* key_in,
+                 int64_t n, double eps, int min_pts, int pts_in_cell, int small_max, int32_t* rows_o, int32_t* cols_o,
+                 int64_t* m_o) {
   if (n < 0) return vcp_fail(ctx, VCP_ERR_ARG, "n < 0");
   if (n == 0) return vcp_fail(ctx, VCP_ERR_EMPTY, "rawData.Min() on an empty list throws (FrmMain.cs:1224)");
   if (pts_in_cell <= 0) return vcp_fail(ctx, VCP_ERR_EMPTY, "Take(0) then cell.Max() throws (FrmMain.cs:1255)");
@@ -451,7 +456,23 @@ int blocks_begin(vcp_ctx* ctx, const double* d_motor_in, bool from_host, const d
   VCP_TRY(ens(ctx, s->motor, (size_t)n * 16));
   if (from_host) VCP_HIP(ctx, hipMemcpyAsync(s->motor.p, h_motor, (size_t)n * 16, hipMemcpyHostToDevice, st));
   else VCP_HIP(ctx, hipMemcpyAsync(s->motor.p, d_motor_in, (size_t)n * 16, hipMemcpyDeviceToDevice, st));
-  const double* motor = s->motor.as<double>();
+  const double* motor_own = s->motor.as<double>();
+  if (key_in) {
+    VCP_TRY(ens(ctx, s->pkey, (size_t)n * 16));
+    VCP_HIP(ctx, hipMemcpyAsync(s->pkey.p, key_in, (size_t)n * 16, from_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
+    // a non-finite motor coordinate would reach DBImproved only; the partition's own check below covers the keys
+    const int rbm = (int)vcp_blocks(n, BT, 1024);
+    VCP_TRY(ens(ctx, s->misc, (size_t)(rbm * 5 + 64) * 8));
+    double* partm = s->misc.as<double>();
+    double* outm = partm + (size_t)rbm * 5;
+    hipLaunchKernelGGL(k_minmax2_part, dim3(rbm), dim3(BT), 0, st, motor_own, n, partm);
+    hipLaunchKernelGGL(k_minmax2_final, dim3(1), dim3(BT), 0, st, partm, rbm, outm);
+    double* hm = reinterpret_cast<double*>(ctx->pinned);
+    VCP_HIP(ctx, hipMemcpyAsync(hm, outm, 5 * 8, hipMemcpyDeviceToHost, st));
+    VCP_HIP(ctx, hipStreamSynchronize(st));
+    if (hm[4] != 0.0) return vcp_fail(ctx, VCP_ERR_ARG, "non-finite motor coordinates");
+  }
+  const double* motor = key_in ? s->pkey.as<double>() : motor_own;  // what the partition reads from here on
   // bounds (FrmMain.cs:1224-1227) and the finiteness check
   const int rb = (int)vcp_blocks(n, BT, 1024);
   VCP_TRY(ens(ctx, s->misc, (size_t)(rb * 5 + 64) * 8));
@@ -462,7 +483,7 @@ int blocks_begin(vcp_ctx* ctx, const double* d_motor_in, bool from_host, const d
   double* h = reinterpret_cast<double*>(ctx->pinned);
   VCP_HIP(ctx, hipMemcpyAsync(h, out, 5 * 8, hipMemcpyDeviceToHost, st));
   VCP_HIP(ctx, hipStreamSynchronize(st));
-  if (h[4] != 0.0) return vcp_fail(ctx, VCP_ERR_ARG, "non-finite motor coordinates");
+  if (h[4] != 0.0) return vcp_fail(ctx, VCP_ERR_ARG, "non-finite partition coordinates");
   s->x_Min = h[0];
   s->x_Max = h[1];
   s->y_Min = h[2];
@@ -515,7 +536,7 @@ int blocks_begin(vcp_ctx* ctx, const double* d_motor_in, bool from_host, const d
   VCP_HIP(ctx, hipMemsetAsync(s->blockstart.p, 0, (size_t)(nb1 + 1) * 4, st));
   hipLaunchKernelGGL(k_mark_key_ends, dim3(nblk(n)), dim3(BT), 0, st, blk_t, n, s->blockstart.as<uint32_t>());
   VCP_TRY(vcp_exclusive_max_scan_u32(ctx, s->blockstart.as<uint32_t>(), s->blockstart.as<uint32_t>(), nb1 + 1, nullptr));
-  hipLaunchKernelGGL(k_gather_motor, dim3(nblk(n)), dim3(BT), 0, st, motor, s->bl.as<uint32_t>(), n,
+  hipLaunchKernelGGL(k_gather_motor, dim3(nblk(n)), dim3(BT), 0, st, motor_own, s->bl.as<uint32_t>(), n,
                      s->motor_bm.as<double>());
   VCP_HIP(ctx, hipGetLastError());
   s->h_blockstart.resize((size_t)nb1 + 1);
@@ -668,7 +689,7 @@ extern "C" {
 void vcp_blocks_state_free(vcp_ctx* ctx) {
   if (!ctx || !ctx->blocks) return;
   BlocksState* s = ctx->blocks;
-  DevBuf* all[] = {&s->motor, &s->raw, &s->rankpos, &s->blockof, &s->bl, &s->motor_bm, &s->blockstart,
+  DevBuf* all[] = {&s->motor, &s->pkey, &s->raw, &s->rankpos, &s->blockof, &s->bl, &s->motor_bm, &s->blockstart,
                    &s->gtwice, &s->gnclus, &s->tmp0, &s->tmp1, &s->tmp2, &s->tmp3, &s->sorttmp, &s->blk_t, &s->csize,
                    &s->cstart, &s->kb, &s->zb, &s->keep, &s->order, &s->newlab, &s->zflag, &s->zlist, &s->zcoords,
                    &s->zlab, &s->misc};
@@ -682,7 +703,26 @@ int vcp_blocks_begin(vcp_ctx* ctx, const double* motor, int64_t n, double eps, i
                      int small_max, int32_t* rows, int32_t* cols, int64_t* nblocks, int64_t* m) {
   if (!ctx) return VCP_ERR_ARG;
   if (n > 0 && !motor) return vcp_fail(ctx, VCP_ERR_ARG, "null buffer");
-  VCP_TRY(blocks_begin(ctx, nullptr, true, motor, n, eps, min_pts, pts_in_cell, small_max, rows, cols, m));
+  VCP_TRY(blocks_begin(ctx, nullptr, true, motor, nullptr, n, eps, min_pts, pts_in_cell, small_max, rows, cols, m));
+  if (nblocks) *nblocks = ctx->blocks->nblocks;
+  return VCP_OK;
+}
+
+int vcp_blocks_begin_keyed(vcp_ctx* ctx, const double* key_xy, const double* motor, int64_t n, double eps, int min_pts,
+                           int pts_in_cell, int small_max, int32_t* rows, int32_t* cols, int64_t* nblocks, int64_t* m) {
+  if (!ctx) return VCP_ERR_ARG;
+  if (n > 0 && (!motor || !key_xy)) return vcp_fail(ctx, VCP_ERR_ARG, "null buffer");
+  VCP_TRY(blocks_begin(ctx, nullptr, true, motor, key_xy, n, eps, min_pts, pts_in_cell, small_max, rows, cols, m));
+  if (nblocks) *nblocks = ctx->blocks->nblocks;
+  return VCP_OK;
+}
+
+int vcp_blocks_begin_keyed_dev(vcp_ctx* ctx, const double* d_key_xy, const double* d_motor, int64_t n, double eps,
+                               int min_pts, int pts_in_cell, int small_max, int32_t* rows, int32_t* cols,
+                               int64_t* nblocks, int64_t* m) {
+  if (!ctx) return VCP_ERR_ARG;
+  if (n > 0 && (!d_motor || !d_key_xy)) return vcp_fail(ctx, VCP_ERR_ARG, "null buffer");
+  VCP_TRY(blocks_begin(ctx, d_motor, false, nullptr, d_key_xy, n, eps, min_pts, pts_in_cell, small_max, rows, cols, m));
   if (nblocks) *nblocks = ctx->blocks->nblocks;
   return VCP_OK;
 }
@@ -691,7 +731,7 @@ int vcp_blocks_begin_dev(vcp_ctx* ctx, const double* d_motor, int64_t n, double 
                          int small_max, int32_t* rows, int32_t* cols, int64_t* nblocks, int64_t* m) {
   if (!ctx) return VCP_ERR_ARG;
   if (n > 0 && !d_motor) return vcp_fail(ctx, VCP_ERR_ARG, "null buffer");
-  VCP_TRY(blocks_begin(ctx, d_motor, false, nullptr, n, eps, min_pts, pts_in_cell, small_max, rows, cols, m));
+  VCP_TRY(blocks_begin(ctx, d_motor, false, nullptr, nullptr, n, eps, min_pts, pts_in_cell, small_max, rows, cols, m));
   if (nblocks) *nblocks = ctx->blocks->nblocks;
   return VCP_OK;
 }
@@ -745,10 +785,19 @@ int vcp_dbscan_blocks(vcp_ctx* ctx, const double* motor, int64_t n, double eps, 
                       int small_max, int32_t* labels, int32_t* block_of, int64_t* merge_order, int64_t* m_out,
                       int32_t* rows, int32_t* cols, int32_t* kept, int32_t* del_sum, int32_t* cluster_amount,
                       int64_t* dist_evals) {
+  return vcp_dbscan_blocks_keyed(ctx, nullptr, motor, n, eps, min_pts, pts_in_cell, small_max, labels, block_of,
+                                 merge_order, m_out, rows, cols, kept, del_sum, cluster_amount, dist_evals);
+}
+
+int vcp_dbscan_blocks_keyed(vcp_ctx* ctx, const double* key_xy, const double* motor, int64_t n, double eps, int min_pts,
+                            int pts_in_cell, int small_max, int32_t* labels, int32_t* block_of, int64_t* merge_order,
+                            int64_t* m_out, int32_t* rows, int32_t* cols, int32_t* kept, int32_t* del_sum,
+                            int32_t* cluster_amount, int64_t* dist_evals) {
   if (!ctx) return VCP_ERR_ARG;
   if (n > 0 && (!motor || !labels)) return vcp_fail(ctx, VCP_ERR_ARG, "null buffer");
   int64_t m = 0, nblocks = 0;
-  VCP_TRY(vcp_blocks_begin(ctx, motor, n, eps, min_pts, pts_in_cell, small_max, rows, cols, &nblocks, &m));
+  if (key_xy) VCP_TRY(vcp_blocks_begin_keyed(ctx, key_xy, motor, n, eps, min_pts, pts_in_cell, small_max, rows, cols, &nblocks, &m));
+  else VCP_TRY(vcp_blocks_begin(ctx, motor, n, eps, min_pts, pts_in_cell, small_max, rows, cols, &nblocks, &m));
   hipStream_t st = ctx->stream;
   VCP_TRY(vcp_ensure(ctx, ctx->b_out0, (size_t)(m + 1) * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_out3, (size_t)n * 4));

@@ -133,8 +133,82 @@ __global__ __launch_bounds__(CT) void k_centroid_final(const double* __restrict_
     for (int a = 0; a < 2; a++) c2[2 * (size_t)(k - 1) + a] = cnt ? s[3 + a] / dn : nan;
 }
 
+// getFixedPtsCentroid (BaseClass/Tools.cs:78-111): the same fixed tree over sum(w X), sum(w Y), sum(w Z), sum(w) with
+// w = 1 where the member's clusterId != 0 and duplicates are ignored, else its ptsCount (:88-101).  X * ptsCount is
+// rounded before it is added, as in the C# (no FMA contraction in this library).
+__global__ __launch_bounds__(CT) void k_chunk_sums_w(const uint32_t* __restrict__ sorted_idx,
+                                                    const uint32_t* __restrict__ segstart,
+                                                    const uint32_t* __restrict__ counts,
+                                                    const uint32_t* __restrict__ chunkstart, int32_t K,
+                                                    const double* __restrict__ xyz, const int32_t* __restrict__ cluster_id,
+                                                    const int32_t* __restrict__ pts_count, int ignore_dup,
+                                                    double* __restrict__ partial) {
+  const uint32_t c = blockIdx.x;
+  int lo = 1, hi = K;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (chunkstart[mid] <= c) lo = mid; else hi = mid - 1;
+  }
+  const int k = lo;
+  const uint32_t within = c - chunkstart[k];
+  const uint32_t beg = segstart[k] + within * CH;
+  const uint32_t cnt = counts[k];
+  const uint32_t end = segstart[k] + (within * CH + CH < cnt ? within * CH + CH : cnt);
+  double s[4] = {0, 0, 0, 0};
+  for (uint32_t t = beg + threadIdx.x; t < end; t += CT) {
+    const uint32_t i = sorted_idx[t];
+    const double x = xyz[3 * (int64_t)i], y = xyz[3 * (int64_t)i + 1], z = xyz[3 * (int64_t)i + 2];
+    if (cluster_id[i] != 0 && ignore_dup) {
+      s[0] += x;
+      s[1] += y;
+      s[2] += z;
+      s[3] += 1.0;
+    } else {
+      const double w = (double)pts_count[i];
+      s[0] += x * w;
+      s[1] += y * w;
+      s[2] += z * w;
+      s[3] += w;  // integers below 2^53: exact
+    }
+  }
+  __shared__ double sm[CT / 64][4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+    double v = wsum(s[a]);
+    if (lane == 0) sm[w][a] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double v = sm[0][threadIdx.x];
+    for (int q = 1; q < CT / 64; q++) v += sm[q][threadIdx.x];
+    partial[(size_t)c * 4 + threadIdx.x] = v;
+  }
+}
+
+__global__ __launch_bounds__(CT) void k_centroid_final_w(const double* __restrict__ partial,
+                                                        const uint32_t* __restrict__ counts,
+                                                        const uint32_t* __restrict__ chunkstart, int32_t K,
+                                                        double* __restrict__ c3, int64_t* __restrict__ inside,
+                                                        uint32_t* __restrict__ empty) {
+  int k = blockIdx.x * CT + threadIdx.x + 1;
+  if (k > K) return;
+  if (counts[k] == 0) atomicAdd(empty, 1u);  // clusList[i].li[0] on an empty list throws (Tools.cs:106)
+  double s[4] = {0, 0, 0, 0};
+  for (uint32_t c = chunkstart[k]; c < chunkstart[k + 1]; c++)
+    for (int a = 0; a < 4; a++) s[a] += partial[(size_t)c * 4 + a];
+  if (inside) inside[k - 1] = (int64_t)s[3];
+  for (int a = 0; a < 3; a++) c3[3 * (size_t)(k - 1) + a] = s[a] / s[3];  // insideNum == 0: 0/0 = NaN, like the C#
+}
+
+struct WeightArgs {
+  const int32_t* cluster_id;
+  const int32_t* pts_count;
+  int ignore_dup;
+};
+
 int centroids_dev(vcp_ctx* ctx, const double* d_xyz, const double* d_motor, const int32_t* d_labels, int64_t n,
-                  int32_t K, double* d_c3, double* d_c2, int64_t* d_counts) {
+                  int32_t K, double* d_c3, double* d_c2, int64_t* d_counts, const WeightArgs* wa = nullptr) {
   hipStream_t st = ctx->stream;
   if (K == 0) return VCP_OK;
   // aux0: counts [K+2] | nch [K+2] ; aux1: keys in/out ; aux2: vals in/out ; aux3: rocprim temp ; aux4: partial
@@ -174,6 +248,20 @@ int centroids_dev(vcp_ctx* ctx, const double* d_xyz, const double* d_motor, cons
   const uint32_t nchunks = hp[4];
   VCP_TRY(vcp_ensure(ctx, ctx->b_aux4, ((size_t)nchunks + 1) * 5 * sizeof(double)));
   double* partial = ctx->b_aux4.as<double>();
+  if (wa) {
+    uint32_t* empty = bad + 2;
+    if (nchunks > 0)
+      hipLaunchKernelGGL(k_chunk_sums_w, dim3(nchunks), dim3(CT), 0, st, vals_out, segstart, counts, nch, K, d_xyz,
+                         wa->cluster_id, wa->pts_count, wa->ignore_dup, partial);
+    hipLaunchKernelGGL(k_centroid_final_w, dim3(vcp_blocks(K, CT)), dim3(CT), 0, st, partial, counts, nch, K, d_c3,
+                       d_counts, empty);
+    VCP_HIP(ctx, hipGetLastError());
+    VCP_HIP(ctx, hipMemcpyAsync(hp, empty, 4, hipMemcpyDeviceToHost, st));
+    VCP_HIP(ctx, hipStreamSynchronize(st));
+    if (hp[0] != 0)
+      return vcp_fail(ctx, VCP_ERR_INDEX, "%u empty groups: clusList[i].li[0] throws (Tools.cs:106)", hp[0]);
+    return VCP_OK;
+  }
   if (nchunks > 0)
     hipLaunchKernelGGL(k_chunk_sums, dim3(nchunks), dim3(CT), 0, st, vals_out, segstart, counts, nch, K, d_xyz, d_motor,
                        partial);
@@ -281,6 +369,38 @@ int vcp_centroids(vcp_ctx* ctx, const double* xyz, const double* motor, const in
     if (counts) VCP_HIP(ctx, hipMemcpyAsync(counts, ctx->b_out2.p, (size_t)K * 8, hipMemcpyDeviceToHost, st));
     VCP_HIP(ctx, hipStreamSynchronize(st));
   }
+  return VCP_OK;
+}
+
+int vcp_centroids_weighted(vcp_ctx* ctx, const double* xyz, const int32_t* group, const int32_t* cluster_id,
+                           const int32_t* pts_count, int64_t n, int32_t K, int ignore_duplication, double* c3,
+                           int64_t* inside_num) {
+  if (!ctx) return VCP_ERR_ARG;
+  if (n < 0 || K < 0 || (n > 0 && (!xyz || !group || !pts_count)) || (K > 0 && !c3))
+    return vcp_fail(ctx, VCP_ERR_ARG, "bad argument");
+  if (n >= 0x7FFFFFF0LL) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "n beyond 32-bit indexing");
+  if (K == 0) return VCP_OK;
+  if (n == 0) return vcp_fail(ctx, VCP_ERR_INDEX, "empty groups: clusList[i].li[0] throws (Tools.cs:106)");
+  VCP_TRY(vcp_bind(ctx));
+  vcp_phase_reset(ctx);
+  hipStream_t st = ctx->stream;
+  VCP_TRY(vcp_ensure(ctx, ctx->b_in0, (size_t)n * 24));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_in1, (size_t)n * 4));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_in2, (size_t)n * 4));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_in3, (size_t)n * 4));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_out0, (size_t)K * 24));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_out2, (size_t)K * 8));
+  VCP_HIP(ctx, hipMemcpyAsync(ctx->b_in0.p, xyz, (size_t)n * 24, hipMemcpyHostToDevice, st));
+  VCP_HIP(ctx, hipMemcpyAsync(ctx->b_in3.p, group, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  VCP_HIP(ctx, hipMemcpyAsync(ctx->b_in1.p, cluster_id ? cluster_id : group, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  VCP_HIP(ctx, hipMemcpyAsync(ctx->b_in2.p, pts_count, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  WeightArgs wa{ctx->b_in1.as<int32_t>(), ctx->b_in2.as<int32_t>(), ignore_duplication ? 1 : 0};
+  VCP_TRY(centroids_dev(ctx, ctx->b_in0.as<double>(), nullptr, ctx->b_in3.as<int32_t>(), n, K, ctx->b_out0.as<double>(),
+                        nullptr, ctx->b_out2.as<int64_t>(), &wa));
+  VCP_HIP(ctx, hipMemcpyAsync(c3, ctx->b_out0.p, (size_t)K * 24, hipMemcpyDeviceToHost, st));
+  if (inside_num) VCP_HIP(ctx, hipMemcpyAsync(inside_num, ctx->b_out2.p, (size_t)K * 8, hipMemcpyDeviceToHost, st));
+  VCP_TRY(vcp_phase_finish(ctx));
+  VCP_HIP(ctx, hipStreamSynchronize(st));
   return VCP_OK;
 }
 

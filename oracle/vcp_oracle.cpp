@@ -255,7 +255,7 @@ int dbscan_canonical_impl(const double* coords, int64_t n, int dim, int metric, 
   }
   Grid g;
   g.build(coords, n, dim, metric == ORC_L2_3D ? 3 : 2, eps);
-  std::vector<uint8_t> core(n, 0), expanding(n, 0);
+  std::vector<uint8_t> core(n, 0), expanding(n, 0), lonely(n, 0);
   for (int64_t i = 0; i < n; i++) {
     int64_t cnt = 0;
     g.for_candidates(i, [&](int64_t j) {
@@ -263,6 +263,7 @@ int dbscan_canonical_impl(const double* coords, int64_t n, int dim, int metric, 
     });
     core[i] = cnt >= (int64_t)min_pts;
     expanding[i] = core[i] && !classed[i];
+    lonely[i] = cnt == 0;  // non-finite coordinate: not even its own neighbour
   }
   UF uf(n);
   for (int64_t i = 0; i < n; i++) {
@@ -312,10 +313,15 @@ int dbscan_canonical_impl(const double* coords, int64_t n, int dim, int metric, 
     }
     if (newlab[i] != 0) {
       labels[i] = newlab[i];
-      classed[i] = 1;
+      // a seed with an EMPTY neighbour list (min_pts <= 0, non-finite point) gets its id (:58) but is never popped, so
+      // never marked classed (:63-65)
+      if (!(expanding[i] && lonely[i])) classed[i] = 1;
     }
   }
-  queries += (int64_t)seed_of.size() + border_twice;
+  // a seed is queried a second time when it is popped from its own neighbour list; a lonely seed never is
+  int64_t lonely_seeds = 0;
+  for (int64_t i : seed_of) lonely_seeds += lonely[i];
+  queries += (int64_t)seed_of.size() - lonely_seeds + border_twice;
   if (cf_out) *cf_out = cf;
   if (dist_evals) *dist_evals = queries * n;
   return ORC_OK;

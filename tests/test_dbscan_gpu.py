@@ -75,6 +75,14 @@ def test_degenerate_and_edge_cases(vcp_ctx, oracle):
     c[17, 0] = np.inf
     c[30, 1] = -np.inf
     _same(vcp_ctx.dbscan(c, 0.2, 3), oracle.dbscan(c, 0.2, 3, literal=True), "nonfinite")
+    # min_pts <= 0 AND non-finite points: each such point seeds a cluster of its own (0 >= minPts) but the empty
+    # neighbour list never marks it classed (BaseClass/DBImproved.cs:58-65, :105-108); also with points classed on entry
+    for mp in (0, -1):
+        _same(vcp_ctx.dbscan(c, 0.2, mp), oracle.dbscan(c, 0.2, mp, literal=True), "nonfinite, minPts %d" % mp)
+        cls = (rng.random(200) < 0.4).astype(np.uint8)
+        lab0 = (cls * 9).astype(np.int32)
+        _same(vcp_ctx.dbscan(c, 0.2, mp, 0, 2, cls, lab0), oracle.dbscan(c, 0.2, mp, 0, 2, cls, lab0, literal=True),
+              "nonfinite, minPts %d, classed on entry" % mp)
     # unrepresentable eps and unquantised doubles
     c = rng.random((3000, 3)) * 4
     for metric in (0, 1, 2):

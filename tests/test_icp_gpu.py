@@ -102,3 +102,48 @@ def test_large_model_goes_through_lds_tiles(vcp_ctx, oracle, nd):
     o = oracle.icp(truth, cen, 1e-9, 100, N.STOP_SSE_DELTA)
     assert g["iters"] == o["iters"]
     assert np.abs(g["R"] - o["R"]).max() < TOL and np.abs(g["T"] - o["T"]).max() < TOL and g["rmse"] < 1e-9
+
+
+def test_grid_nn_30k_x_30k_tie_heavy(vcp_ctx, oracle):
+    """Models beyond 512 points are binned and searched through the grid (csrc/nngrid.hpp): the index must still be the
+    one FindClosestPointSet's sequential strict-`<` scan returns (BaseClass/ICP.cs:224-250).  30 k x 30 k on a coarse
+    lattice: thousands of exact distance ties and duplicated model points; plus queries far outside the model (ring
+    search runs out and falls back to the whole set), planar and collinear models (degenerate grid axes)."""
+    rng = np.random.default_rng(30)
+    model = rng.integers(0, 60, size=(30_000, 3)).astype(np.float64) * 0.5 + 500.0
+    data = rng.integers(0, 120, size=(30_000, 3)).astype(np.float64) * 0.25 + 500.0
+    data[:200] += 1000.0  # far outside the model's box
+    data[200:300] -= 750.0
+    sums, nn = vcp_ctx.icp_sums(model, data)
+    assert np.array_equal(nn, oracle.find_closest(model, data))
+    assert np.allclose(sums, oracle.icp_sums(model, data), rtol=1e-12, atol=1e-3)
+    for flat in (1, 2):  # planar (z constant), collinear (y and z constant)
+        m2 = model[:5000].copy()
+        m2[:, 3 - flat:] = 7.0
+        d2 = data[:5000].copy()
+        _, nn2 = vcp_ctx.icp_sums(m2, d2)
+        assert np.array_equal(nn2, oracle.find_closest(m2, d2))
+    same = np.repeat(model[:1], 1000, axis=0)  # every model point identical: one cell, index 0 wins everywhere
+    _, nn3 = vcp_ctx.icp_sums(same, data[:2000])
+    assert not nn3.any()
+    # real-valued clouds (no ties), clustered: dense and empty cells side by side
+    model = np.concatenate([rng.normal(0, 1, (20_000, 3)), rng.normal(40, 0.05, (10_000, 3))])
+    data = np.concatenate([rng.normal(0, 3, (15_000, 3)), rng.normal(40, 0.2, (15_000, 3))])
+    _, nn4 = vcp_ctx.icp_sums(model, data)
+    assert np.array_equal(nn4, oracle.find_closest(model, data))
+    # the whole K x K ICP through the grid
+    cen = np.round(rng.uniform(0, 300.0, (30_000, 3)) * 1024) / 1024
+    truth = cen @ synth.rotation_about((1.0, 1.0, 1.0), 0.05).T + np.array([0.03, -0.02, 0.01])
+    g = vcp_ctx.icp(truth, cen, 1e-9, 100, N.STOP_SSE_DELTA)
+    o = oracle.icp(truth, cen, 1e-9, 100, N.STOP_SSE_DELTA)
+    assert g["iters"] == o["iters"]
+    assert np.abs(g["R"] - o["R"]).max() < TOL and np.abs(g["T"] - o["T"]).max() < TOL and abs(g["rmse"] - o["rmse"]) < TOL
+
+
+def test_non_finite_model_keeps_full_scan(vcp_ctx, oracle):
+    rng = np.random.default_rng(4)
+    model = rng.random((3000, 3)) * 10
+    model[17, 1] = np.inf
+    data = rng.random((5000, 3)) * 10
+    _, nn = vcp_ctx.icp_sums(model, data)
+    assert np.array_equal(nn, oracle.find_closest(model, data))

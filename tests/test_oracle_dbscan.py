@@ -115,3 +115,24 @@ def test_db_dead_class_literal(oracle):
     shown = np.array([1, 1, 0, 1], np.uint8)
     r = oracle.db_literal(c, 0.5, 3, shown)
     assert r["labels"].tolist() == [1, 1, 0, 1] and r["points_amount"] == 3
+
+
+def test_literal_equals_canonical_with_non_finite_points_and_min_pts_le_0(oracle):
+    """A point with a NaN / infinite coordinate is nobody's neighbour, not even its own.  With minPts <= 0 it still seeds
+    a cluster (0 >= minPts, DBImproved.cs:105), takes the id (:58), but is never popped from its empty list: not classed
+    (:63-65) and queried once, not twice.  The order-free formulation must say the same."""
+    rng = np.random.default_rng(3)
+    for t in range(300):
+        n = int(rng.integers(5, 60))
+        c = rng.integers(0, 6, size=(n, 2)).astype(np.float64)
+        k = rng.integers(0, n, 3)
+        c[k[0]] = np.nan
+        c[k[1], 0] = np.inf
+        mp = int(rng.integers(-1, 3))
+        cls = (rng.random(n) < 0.3).astype(np.uint8)
+        lab = (cls * 7).astype(np.int32)
+        a = oracle.dbscan(c, 1.0, mp, 0, 2, cls, lab, literal=True)
+        b = oracle.dbscan(c, 1.0, mp, 0, 2, cls, lab, literal=False)
+        for key in ("labels", "classed", "is_key"):
+            assert np.array_equal(a[key], b[key]), (t, key)
+        assert a["cf"] == b["cf"] and a["evals"] == b["evals"], t

@@ -87,6 +87,35 @@ def test_match(vcp_ctx, oracle):
     assert e.value.code == -2
 
 
+def test_match_long_truth_list_through_the_grid(vcp_ctx, oracle):
+    """T > 512: the truths are binned (csrc/nngrid.hpp).  RecorrectMatchingPtsByDistance compares correctly rounded
+    sqrt distances with strict `<` (FrmMain.cs:3588-3618, getDisP :829-835): ties AFTER the sqrt go to the lowest truth
+    index too.  30 k x 30 k on a lattice (exact ties), duplicates, centroids far away, non-finite centroid."""
+    rng = np.random.default_rng(12)
+    K = T = 30_000
+    truths = rng.integers(0, 80, size=(T, 3)).astype(np.float64) * 0.5
+    centers = rng.integers(0, 160, size=(K, 3)).astype(np.float64) * 0.25
+    truths[9000:9100] = truths[:100]
+    centers[:100] += 500.0
+    M = np.eye(4)
+    o = oracle.match(centers, truths, M, 0.6)
+    g = vcp_ctx.match(centers, truths, M, 0.6)
+    for k in ("matched_xyz", "nearest", "nearest_dist", "is_matched"):
+        assert np.array_equal(o[k], g[k]), k
+    assert o["count"] == g["count"]
+    # generic positions + a rigid transform; nearly equal distances that the sqrt merges
+    truths = rng.random((T, 3)) * 200
+    centers = truths[rng.permutation(T)] + rng.normal(0, 1e-9, (K, 3))
+    centers[5] = np.nan
+    centers[6] = np.inf
+    M[:3, :3] = synth.rotation_about((0, 0, 1), 0.01)
+    M[:3, 3] = (0.05, -0.025, 0.0125)
+    o = oracle.match(centers, truths, M, 0.5)
+    g = vcp_ctx.match(centers, truths, M, 0.5)
+    assert np.array_equal(o["nearest"], g["nearest"]) and np.array_equal(o["is_matched"], g["is_matched"])
+    assert np.array_equal(o["nearest_dist"], g["nearest_dist"], equal_nan=True) and o["count"] == g["count"]
+
+
 def test_minimal_bounding_circles(vcp_ctx, oracle):
     """Tools.getCircles / Geometry.FindMinimalBoundingCircle: bit-exact vs the literal port."""
     # hand-checkable: the circumcircle of a square, and an obtuse triangle (circle on the longest side)

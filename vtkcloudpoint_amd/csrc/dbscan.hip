@@ -1143,6 +1143,28 @@ __global__ __launch_bounds__(TPB) void k_degenerate(const uint8_t* __restrict__ 
   if (is_classed) is_classed[i] = cls ? 1 : 0;  // expandCluster never marks the seed itself
 }
 
+// ---- min_pts <= 0 with non-finite coordinates -------------------------------------------------------------
+// A point with a NaN / infinite coordinate has no neighbour, not even itself.  With min_pts <= 0 it is still "core"
+// (0 >= minPts, BaseClass/DBImproved.cs:105): it seeds a cluster of its own, gets the id (:58), but expandCluster's
+// loop over the EMPTY neighbour list never marks it classed (:63-65).  The label word has no spare bit for this, and
+// the host knows both conditions before the first kernel, so the rare case gets its own pass over caller order.
+template <int GD>
+__global__ __launch_bounds__(TPB) void k_lonely_seeds(const double* __restrict__ c, int64_t n, int stride,
+                                                     const uint8_t* __restrict__ in_classed,
+                                                     uint8_t* __restrict__ is_classed,
+                                                     unsigned long long* __restrict__ lonely_seeds) {
+  int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  bool finite = true;
+#pragma unroll
+  for (int a = 0; a < GD; a++) finite = finite && isfinite(c[i * stride + a]);
+  if (finite) return;
+  const bool cls = in_classed && in_classed[i];
+  if (is_classed) is_classed[i] = cls ? 1 : 0;
+  // such a seed is queried once (main loop), not twice: it is never popped from its own, empty, list
+  if (!cls) atomicAdd(lonely_seeds, 1ull);
+}
+
 // ---- staged (slab) calls: exact DBSCAN over several GPUs (distributed.exact_slabs) ---------------------
 // After the component build the caller needs, per point, the seed of its LOCAL component (smallest ord) and
 // the list of local components; it resolves them against the other ranks' and comes back with, per local
@@ -1434,7 +1456,7 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   uint32_t* clseed = ctx->b_clseed.as<uint32_t>();
   uint32_t* labk = ctx->b_labk.as<uint32_t>();
   int32_t* sgroup = GROUPED ? ctx->b_sgroup.as<int32_t>() : nullptr;
-  // [0] unused, [1] border points queried twice, [2] seed total (u32), [3] grouped evals, [4..36) unclassed slots
+  // [0] lonely seeds (min_pts <= 0, non-finite points), [1] border points queried twice, [2] seed total (u32), [3] grouped evals, [4..36) unclassed slots
   unsigned long long* counters = reinterpret_cast<unsigned long long*>(d_bounds + 8);
   uint32_t* d_total = reinterpret_cast<uint32_t*>(counters + 2);
 
@@ -1585,6 +1607,9 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
                        GROUPED ? ext->d_groupstart : nullptr, seedflag, seedpref, cf_in, d_labels, d_is_core, d_is_classed,
                        counters);
   }
+  if (!GROUPED && min_pts <= 0 && !all_finite)
+    hipLaunchKernelGGL(k_lonely_seeds<GD>, dim3(nb), dim3(TPB), 0, st, d_coords, n, stride, d_in_classed, d_is_classed,
+                       counters);
   if (GROUPED) {
     hipLaunchKernelGGL(k_group_stats, dim3(vcp_blocks(G, TPB)), dim3(TPB), 0, st, G, glo, ghi, ext->d_groupstart,
                        seedflag, seedpref, ext->d_group_twice, ext->d_group_nclus, counters + 3);
@@ -1603,7 +1628,7 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
     for (int k = 0; k < 32; k++) unclassed += hc[4 + k];
   }
   if (cf_out) *cf_out = cf_in + (int32_t)K;
-  if (dist_evals) *dist_evals = GROUPED ? (int64_t)hc[3] : (int64_t)(unclassed + hc[1] + K) * n;
+  if (dist_evals) *dist_evals = GROUPED ? (int64_t)hc[3] : (int64_t)(unclassed + hc[1] + K - hc[0]) * n;
   return VCP_OK;
 }
 

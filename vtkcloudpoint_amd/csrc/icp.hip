@@ -21,6 +21,7 @@
 #include <cstring>
 #include <vector>
 
+#include "nngrid.hpp"
 #include "vcp_ctx.hpp"
 
 namespace {
@@ -109,13 +110,16 @@ __global__ __launch_bounds__(ITPB) void k_model32(const double* __restrict__ m, 
 // broadcast).  The scalar-cache path is the faster one while the model fits that cache (C3: 100 points); a model
 // of thousands of points (ICP of cluster centroids against the truth list, MainForm.ICP's real use) makes every
 // scalar load an L2 round trip, 30x slower than the tiled form.
+// NNMODE 2: the model has been binned (nngrid.hpp): every lane searches the cells round its own transformed point --
+// O(1) candidates per data point instead of the whole model, same exact binary64 decision and tie rule.
 constexpr int MTILE = 1024;
-template <int TB, bool TILED>
+template <int TB, int NNMODE>
 __global__ __launch_bounds__(TB) void k_icp_pass(const double* __restrict__ model, const float4* __restrict__ model32,
                                                 int nm, const double* __restrict__ data, int64_t nd,
                                                 const IcpState* __restrict__ st, double* __restrict__ partial,
-                                                int32_t* __restrict__ nn) {
+                                                int32_t* __restrict__ nn, NNGrid ng) {
   if (st->done) return;
+  constexpr bool TILED = NNMODE == 1, GRID = NNMODE == 2;
   __shared__ float4 tile[TILED ? MTILE : 1];
   double R[9], T[3];
 #pragma unroll
@@ -147,6 +151,11 @@ __global__ __launch_bounds__(TB) void k_icp_pass(const double* __restrict__ mode
       acc += R[3 * r + 2] * d2;
       p[r] = acc + T[r];
     }
+    int order = 0;
+    if (GRID) {
+      double bestv;
+      nng::query<false>(ng, p, order, bestv);
+    } else {
     const double pc0 = p[0] - cen0, pc1 = p[1] - cen1, pc2 = p[2] - cen2;
     const float q0 = (float)pc0, q1 = (float)pc1, q2 = (float)pc2;
     const double S = fmax(mmax, fmax(fabs(pc0), fmax(fabs(pc1), fabs(pc2))));
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(TB) void k_icp_pass(const double* __restrict__ mode
       j1 = lt ? j : j1;
       b1 = lt ? sc : b1;
     }
-    int order = j1;
+    order = j1;
     const bool amb = !(b2 > b1 + tol2);
     if (TILED) {
       // second sweep over the tiles for the lanes whose screening left more than one candidate; the whole
@@ -268,6 +277,7 @@ __global__ __launch_bounds__(TB) void k_icp_pass(const double* __restrict__ mode
         }
       }
     }
+    }  // !GRID
     if (!live) continue;
     if (nn) nn[i] = order;
     const double y0 = model[3 * order], y1 = model[3 * order + 1], y2 = model[3 * order + 2];
@@ -490,7 +500,16 @@ int icp_run(vcp_ctx* ctx, const double* d_model, int64_t nm, const double* d_dat
   hipStream_t st = ctx->stream;
   // small data sets: one wave per workgroup so that they reach more CUs; large models: LDS tiles
   const bool small = nd <= (int64_t)64 * ICP_MAX_BLOCKS;
-  const bool tiled = nm > 512;
+  // models beyond the scalar cache: binned once per call (they do not move), grid search per data point; a model with
+  // non-finite coordinates keeps the LDS-tiled full scan
+  NNGrid ng{};
+  bool grid = false;
+  if (nm > 512) {
+    const int grc = vcp_nngrid_build(ctx, d_model, nm, &ng);
+    if (grc == VCP_OK) grid = true;
+    else if (grc != VCP_ERR_UNSUPPORTED) return grc;
+  }
+  const bool tiled = nm > 512 && !grid;
   const int tb = small ? 64 : ITPB;
   const int nb = (int)vcp_blocks(nd, tb, ICP_MAX_BLOCKS);
   VCP_TRY(vcp_ensure(ctx, ctx->b_icp_part, (size_t)ICP_MAX_BLOCKS * 16 * sizeof(double) + sizeof(IcpState) + 256));
@@ -508,11 +527,13 @@ int icp_run(vcp_ctx* ctx, const double* d_model, int64_t nm, const double* d_dat
     const int batch = mode == MODE_SUMS_ONLY ? 1 : std::min(ICP_BATCH, max_iter - launched);
     for (int b = 0; b < batch; b++) {
 #define VCP_PASS(TBV, TL) \
-  hipLaunchKernelGGL((k_icp_pass<TBV, TL>), dim3(nb), dim3(TBV), 0, st, d_model, model32, (int)nm, d_data, nd, d_st, part, d_nn)
-      if (small && tiled) VCP_PASS(64, true);
-      else if (small) VCP_PASS(64, false);
-      else if (tiled) VCP_PASS(ITPB, true);
-      else VCP_PASS(ITPB, false);
+  hipLaunchKernelGGL((k_icp_pass<TBV, TL>), dim3(nb), dim3(TBV), 0, st, d_model, model32, (int)nm, d_data, nd, d_st, part, d_nn, ng)
+      if (small && grid) VCP_PASS(64, 2);
+      else if (grid) VCP_PASS(ITPB, 2);
+      else if (small && tiled) VCP_PASS(64, 1);
+      else if (small) VCP_PASS(64, 0);
+      else if (tiled) VCP_PASS(ITPB, 1);
+      else VCP_PASS(ITPB, 0);
 #undef VCP_PASS
       hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(ITPB), 0, st, part, nb, d_st, (long long)nd, tol, stop_rule, max_iter,
                          mode);

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <vector>
 
+#include "nngrid.hpp"
 #include "vcp_ctx.hpp"
 
 namespace {
@@ -17,10 +18,13 @@ struct M16 {
   double m[16];
 };
 
+// GRID: the truths have been binned (nngrid.hpp); the search compares (sqrt distance, truth index) pairs, i.e. returns
+// what the sequential strict-`<` scan over the correctly rounded distances returns.
+template <bool GRID>
 __global__ __launch_bounds__(MT) void k_match(const double* __restrict__ centers, int K, const double* __restrict__ truths,
                                              int T, M16 M, double max_dist, double* __restrict__ mxyz,
                                              uint8_t* __restrict__ is_matched, int32_t* __restrict__ nearest,
-                                             double* __restrict__ ndist, uint32_t* __restrict__ count) {
+                                             double* __restrict__ ndist, uint32_t* __restrict__ count, NNGrid ng) {
   int j = blockIdx.x * MT + threadIdx.x;
   bool hit = false;
   if (j < K) {
@@ -35,16 +39,23 @@ __global__ __launch_bounds__(MT) void k_match(const double* __restrict__ centers
     }
     int best = 0;
     double bd;
-    {
-      double dx = truths[0] - m[0], dy = truths[1] - m[1], dz = truths[2] - m[2];
+    if (GRID) {
+      nng::query<true>(ng, m, best, bd);
+      // the distance the C# holds for the winner (NaN / infinity included: the query only orders finite values)
+      double dx = truths[3 * best] - m[0], dy = truths[3 * best + 1] - m[1], dz = truths[3 * best + 2] - m[2];
       bd = sqrt(dx * dx + dy * dy + dz * dz);
-    }
-    for (int i = 1; i < T; i++) {
-      double dx = truths[3 * i] - m[0], dy = truths[3 * i + 1] - m[1], dz = truths[3 * i + 2] - m[2];
-      double d = sqrt(dx * dx + dy * dy + dz * dz);
-      if (d < bd) {
-        bd = d;
-        best = i;
+    } else {
+      {
+        double dx = truths[0] - m[0], dy = truths[1] - m[1], dz = truths[2] - m[2];
+        bd = sqrt(dx * dx + dy * dy + dz * dz);
+      }
+      for (int i = 1; i < T; i++) {
+        double dx = truths[3 * i] - m[0], dy = truths[3 * i + 1] - m[1], dz = truths[3 * i + 2] - m[2];
+        double d = sqrt(dx * dx + dy * dy + dz * dz);
+        if (d < bd) {
+          bd = d;
+          best = i;
+        }
       }
     }
     nearest[j] = best;
@@ -279,9 +290,23 @@ extern "C" int vcp_match(vcp_ctx* ctx, const double* centers, int32_t K, const d
   VCP_HIP(ctx, hipMemsetAsync(cnt, 0, 16, st));
   M16 m;
   for (int i = 0; i < 16; i++) m.m[i] = M[i];
-  hipLaunchKernelGGL(k_match, dim3(vcp_blocks(K, MT)), dim3(MT), 0, st, ctx->b_in0.as<double>(), K,
-                     ctx->b_in2.as<double>(), T, m, max_dist, ctx->b_out0.as<double>(), ctx->b_out1.as<uint8_t>(),
-                     ctx->b_out3.as<int32_t>(), ctx->b_out2.as<double>(), cnt);
+  // long truth lists are binned once (FrmMain.cs:3588-3618 scans all of them per centroid); non-finite truths keep
+  // the full scan
+  NNGrid ng{};
+  bool grid = false;
+  if (T > 512) {
+    const int grc = vcp_nngrid_build(ctx, ctx->b_in2.as<double>(), T, &ng);
+    if (grc == VCP_OK) grid = true;
+    else if (grc != VCP_ERR_UNSUPPORTED) return grc;
+  }
+  if (grid)
+    hipLaunchKernelGGL(k_match<true>, dim3(vcp_blocks(K, MT)), dim3(MT), 0, st, ctx->b_in0.as<double>(), K,
+                       ctx->b_in2.as<double>(), T, m, max_dist, ctx->b_out0.as<double>(), ctx->b_out1.as<uint8_t>(),
+                       ctx->b_out3.as<int32_t>(), ctx->b_out2.as<double>(), cnt, ng);
+  else
+    hipLaunchKernelGGL(k_match<false>, dim3(vcp_blocks(K, MT)), dim3(MT), 0, st, ctx->b_in0.as<double>(), K,
+                       ctx->b_in2.as<double>(), T, m, max_dist, ctx->b_out0.as<double>(), ctx->b_out1.as<uint8_t>(),
+                       ctx->b_out3.as<int32_t>(), ctx->b_out2.as<double>(), cnt, ng);
   VCP_HIP(ctx, hipGetLastError());
   uint32_t* hp = reinterpret_cast<uint32_t*>(ctx->pinned);
   if (matched_xyz) VCP_HIP(ctx, hipMemcpyAsync(matched_xyz, ctx->b_out0.p, (size_t)K * 24, hipMemcpyDeviceToHost, st));

@@ -88,8 +88,12 @@ int vcp_timing_get(vcp_ctx* ctx, int i, const char** name, float* ms);
  *                   (BC/DBImproved.cs:87 relabels unconditionally); otherwise it is untouched
  * coords     [n*dim] doubles, point-major (x,y[,z]); dim 2 or 3; the 2-D metrics read x,y
  * cf_in      DBImproved.cf before the call (FrmMain.cs:1509 presets it)
- * in_mask    ifShown filter of BC/DB.cs:40,63,98 -- must be NULL (VCP_SIGNED_SUM_2D / masks are
- *            the dead DB class: VCP_ERR_UNSUPPORTED on the GPU)
+ * in_mask    ifShown filter of BC/DB.cs:40,63,98 -- only with VCP_SIGNED_SUM_2D, the dead v1.0 class DB
+ *            (BC/DB.cs:14-115, FrmMain.cs:38): signed distance dx + dy on (x, y), clusters numbered from cf_in + 1,
+ *            dist_evals = DB.iritatorNum, DB.pointsAmount = the number of shown points.  That class needs eps >= 0
+ *            and finite coordinates, and coordinates for which its floating-point relation is provably the 1-D
+ *            relation on x + y (a common binary grid, or no pair within rounding of the threshold); otherwise
+ *            VCP_ERR_UNSUPPORTED (csrc/dbdead.hip)
  * in_classed NULL = nobody classed and labels start at 0 (what every caller sets up,
  *            FrmMain.cs:1219-1223, :1512-1515); else Point3D.isClassed on entry and `labels`
  *            is read as Point3D.clusterId on entry

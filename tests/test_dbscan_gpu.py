@@ -89,10 +89,43 @@ def test_degenerate_and_edge_cases(vcp_ctx, oracle):
         _same(vcp_ctx.dbscan(c, 0.1, 4, metric), oracle.dbscan(c, 0.1, 4, metric, literal=True), "raw doubles")
 
 
-def test_unsupported_dead_class(vcp_ctx):
-    c = np.zeros((4, 2))
+def test_dead_class_DB_on_the_gpu(vcp_ctx, oracle):
+    """BaseClass/DB.cs (signed dx + dy, ifShown, ids from 1) through the C-ABI vs the literal transcription: labels,
+    isClassed, isKeyPoint, clusterAmount, iritatorNum -- random clouds on a binary grid (exact ties at the threshold),
+    masks, points classed on entry, minPts <= 0, eps 0."""
+    rng = np.random.default_rng(17)
+    for t in range(400):
+        n = int(rng.integers(1, 120))
+        c = rng.integers(-20, 20, size=(n, 2)).astype(np.float64) * (0.25 if t % 3 else 1.0)
+        eps = float(rng.choice([0.0, 0.25, 0.5, 1.0, 2.5, 40.0]))
+        mp = int(rng.integers(-1, 8))
+        shown = None if t % 4 == 0 else (rng.random(n) < 0.8).astype(np.uint8)
+        cls = None if t % 5 < 2 else (rng.random(n) < 0.3).astype(np.uint8)
+        lab0 = None if cls is None else (cls * rng.integers(1, 5, n)).astype(np.int32)
+        o = oracle.db_literal(c, eps, mp, shown, cls, lab0)
+        g = vcp_ctx.dbscan(c, eps, mp, N.SIGNED_SUM_2D, 0, cls, lab0, in_mask=shown)
+        what = "trial %d n=%d eps=%g mp=%d" % (t, n, eps, mp)
+        assert np.array_equal(g["labels"], o["labels"]), what
+        assert np.array_equal(g["is_classed"], o["classed"]), what
+        assert np.array_equal(g["is_core"], o["is_key"]), what
+        assert g["cf"] == o["cluster_amount"] and g["evals"] == o["evals"], what
+    # generic doubles: accepted when no pair sits within rounding of the threshold ...
+    c = rng.random((3000, 2)) * 50
+    o = oracle.db_literal(c, 0.37, 4)
+    g = vcp_ctx.dbscan(c, 0.37, 4, N.SIGNED_SUM_2D)
+    assert np.array_equal(g["labels"], o["labels"]) and g["cf"] == o["cluster_amount"] and g["evals"] == o["evals"]
+    # ... refused when one does and the coordinates share no binary grid; e < 0 and non-finite points are refused too
+    c = np.array([[0.1, 0.2], [0.1 + 0.3, 0.2], [5.0, 1.0 / 3.0]])
     with pytest.raises(N.VcpError) as e:
-        vcp_ctx.dbscan(c, 0.5, 2, N.SIGNED_SUM_2D)
+        vcp_ctx.dbscan(c, 0.3, 1, N.SIGNED_SUM_2D)
+    assert e.value.code == -8
+    for bad_c, bad_eps in ((np.zeros((4, 2)), -0.5), (np.array([[0.0, np.nan], [1.0, 1.0]]), 0.5)):
+        with pytest.raises(N.VcpError) as e:
+            vcp_ctx.dbscan(bad_c, bad_eps, 2, N.SIGNED_SUM_2D)
+        assert e.value.code == -8
+    # a mask with the live class is still refused
+    with pytest.raises(N.VcpError) as e:
+        vcp_ctx.dbscan(np.zeros((4, 2)), 0.5, 2, N.L1_2D, in_mask=np.ones(4, np.uint8))
     assert e.value.code == -8
 
 

@@ -4,7 +4,7 @@ import pytest
 
 from vtkcloudpoint_amd import synth
 from vtkcloudpoint_amd.datamodel import ClusObj, Point3D, motor_array, points_from_arrays, xyz_array
-from vtkcloudpoint_amd.dbscan import DB, DBImproved, NotSupportedError
+from vtkcloudpoint_amd.dbscan import DB, DBImproved
 from vtkcloudpoint_amd.icp import ICP, Matrix, MException
 from vtkcloudpoint_amd.tools import Tools
 
@@ -27,8 +27,30 @@ def test_getdisp_and_counter():
     assert DBImproved.iritatorNum == before + 1
     a.X, a.Y, b.X, b.Y = 1.0, 1.0, 0.25, 3.0
     assert DB.getDisP(a, b) == 0.75 - 2.0  # signed sum, DB.cs:21
-    with pytest.raises(NotSupportedError):
-        DB().dbscan([a, b], 1.0, 2)
+
+
+def test_db_statics_follow_the_csharp(oracle):
+    """DB.isKeyPoint / DB.expandCluster are public statics of the v1.0 class (BaseClass/DB.cs:33,57): the host-side
+    mirrors, driven by DB.dbscan's own main loop (:92-115), must reproduce the literal transcription."""
+    rng = np.random.default_rng(2)
+    for _ in range(40):
+        n = int(rng.integers(2, 40))
+        xy = rng.integers(-6, 6, size=(n, 2)).astype(np.float64) * 0.5
+        shown = rng.random(n) < 0.8
+        eps, mp = float(rng.choice([0.0, 0.5, 1.5])), int(rng.integers(1, 5))
+        pts = [Point3D(x, y, 0.0, 0, bool(s)) for (x, y), s in zip(xy, shown)]
+        c = 0
+        for p in pts:  # DB.cs:95-112
+            if not p.ifShown or p.isClassed:
+                continue
+            tmp = DB.isKeyPoint(pts, p, eps, mp)
+            if len(tmp) >= mp:
+                c += 1
+                DB.expandCluster(p, tmp, c, eps, mp, pts)
+        o = oracle.db_literal(xy, eps, mp, shown.astype(np.uint8))
+        assert [p.clusterId for p in pts] == o["labels"].tolist() and c == o["cluster_amount"]
+        assert [int(p.isClassed) for p in pts] == o["classed"].tolist()
+        assert [int(p.isKeyPoint) for p in pts] == o["is_key"].tolist()
 
 
 def test_matrix_slice():

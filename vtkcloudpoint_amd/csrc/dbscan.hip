@@ -1715,10 +1715,23 @@ int vcp_dbscan_engine(vcp_ctx* ctx, const double* d_coords, int64_t n, int strid
   if (!ctx) return VCP_ERR_ARG;
   if (n < 0) return vcp_fail(ctx, VCP_ERR_ARG, "n < 0");
   if (stride != 2 && stride != 3) return vcp_fail(ctx, VCP_ERR_ARG, "dim must be 2 or 3");
-  if (metric == VCP_SIGNED_SUM_2D)
-    return vcp_fail(ctx, VCP_ERR_UNSUPPORTED,
-                    "VCP_SIGNED_SUM_2D is the dead DB class (BaseClass/DB.cs:21, FrmMain.cs:38); not built for the GPU");
   if (metric < 0 || metric > 3) return vcp_fail(ctx, VCP_ERR_ARG, "unknown metric %d", metric);
+  if (metric == VCP_SIGNED_SUM_2D) {  // the dead v1.0 class DB (BaseClass/DB.cs): csrc/dbdead.hip
+    if (ext) return vcp_fail(ctx, VCP_ERR_ARG, "DB has no grouped / staged form");
+    if (n >= 0x7FFFFFF0LL) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "n beyond 32-bit indexing");
+    if (n > 0 && (!d_coords || !d_labels)) return vcp_fail(ctx, VCP_ERR_ARG, "null buffer");
+    VCP_TRY(vcp_bind(ctx));
+    vcp_phase_reset(ctx);
+    if (ctx->slab) ctx->slab->valid = false;
+    if (n == 0) {
+      if (cf_out) *cf_out = cf_in;
+      if (dist_evals) *dist_evals = 0;
+      ctx->last_timing.clear();
+      return VCP_OK;
+    }
+    return vcp_db_engine(ctx, d_coords, n, stride, eps, min_pts, cf_in, nullptr, d_in_classed, d_labels, d_is_core,
+                         d_is_classed, cf_out, dist_evals);
+  }
   if (metric == VCP_L2_3D && stride != 3) return vcp_fail(ctx, VCP_ERR_ARG, "VCP_L2_3D needs dim 3");
   if (n >= 0x3FFFFFF0LL) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "n beyond 30-bit indexing");
   if (n > 0 && (!d_coords || !d_labels)) return vcp_fail(ctx, VCP_ERR_ARG, "null buffer");
@@ -1843,9 +1856,9 @@ int vcp_dbscan(vcp_ctx* ctx, const double* coords, int64_t n, int dim, int metri
                int32_t cf_in, const uint8_t* in_mask, const uint8_t* in_classed, int32_t* labels,
                uint8_t* is_core, uint8_t* is_classed, int32_t* cf_out, int64_t* dist_evals) {
   if (!ctx) return VCP_ERR_ARG;
-  if (in_mask)
+  if (in_mask && metric != VCP_SIGNED_SUM_2D)
     return vcp_fail(ctx, VCP_ERR_UNSUPPORTED,
-                    "ifShown masks belong to the dead DB class (BaseClass/DB.cs:40); not built for the GPU");
+                    "ifShown masks belong to the DB class (BaseClass/DB.cs:40): use metric VCP_SIGNED_SUM_2D");
   if (n < 0) return vcp_fail(ctx, VCP_ERR_ARG, "n < 0");
   if (dim != 2 && dim != 3) return vcp_fail(ctx, VCP_ERR_ARG, "dim must be 2 or 3");
   if (n > 0 && (!coords || !labels)) return vcp_fail(ctx, VCP_ERR_ARG, "null buffer");
@@ -1864,9 +1877,22 @@ int vcp_dbscan(vcp_ctx* ctx, const double* coords, int64_t n, int dim, int metri
       VCP_HIP(ctx, hipMemcpyAsync(ctx->b_out0.p, labels, (size_t)n * 4, hipMemcpyHostToDevice, st));
     }
   }
-  int rc = vcp_dbscan_dev(ctx, ctx->b_in0.as<double>(), n, dim, metric, eps, min_pts, cf_in,
-                          in_classed ? ctx->b_in1.as<uint8_t>() : nullptr, ctx->b_out0.as<int32_t>(),
-                          ctx->b_out1.as<uint8_t>(), ctx->b_out2.as<uint8_t>(), cf_out, dist_evals);
+  int rc;
+  if (metric == VCP_SIGNED_SUM_2D && n > 0) {
+    if (in_mask) {
+      VCP_TRY(vcp_ensure(ctx, ctx->b_in2, nn));
+      VCP_HIP(ctx, hipMemcpyAsync(ctx->b_in2.p, in_mask, (size_t)n, hipMemcpyHostToDevice, st));
+    }
+    vcp_phase_reset(ctx);
+    if (ctx->slab) ctx->slab->valid = false;
+    rc = vcp_db_engine(ctx, ctx->b_in0.as<double>(), n, dim, eps, min_pts, cf_in,
+                       in_mask ? ctx->b_in2.as<uint8_t>() : nullptr, in_classed ? ctx->b_in1.as<uint8_t>() : nullptr,
+                       ctx->b_out0.as<int32_t>(), ctx->b_out1.as<uint8_t>(), ctx->b_out2.as<uint8_t>(), cf_out, dist_evals);
+  } else {
+    rc = vcp_dbscan_dev(ctx, ctx->b_in0.as<double>(), n, dim, metric, eps, min_pts, cf_in,
+                        in_classed ? ctx->b_in1.as<uint8_t>() : nullptr, ctx->b_out0.as<int32_t>(),
+                        ctx->b_out1.as<uint8_t>(), ctx->b_out2.as<uint8_t>(), cf_out, dist_evals);
+  }
   if (rc != VCP_OK) return rc;
   if (n > 0) {
     VCP_HIP(ctx, hipMemcpyAsync(labels, ctx->b_out0.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));

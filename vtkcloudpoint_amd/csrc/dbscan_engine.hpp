@@ -26,3 +26,8 @@ int vcp_dbscan_engine(vcp_ctx* ctx, const double* d_coords, int64_t n, int strid
                       int min_pts, int32_t cf_in, const uint8_t* d_in_classed, int32_t* d_labels,
                       uint8_t* d_is_core, uint8_t* d_is_classed, int32_t* cf_out, int64_t* dist_evals,
                       const DbscanExt* ext);
+
+// The dead v1.0 class DB (BaseClass/DB.cs:14-115), csrc/dbdead.hip: signed-sum metric on (X, Y), ifShown mask.
+int vcp_db_engine(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, double eps, int min_pts, int32_t cf_in,
+                  const uint8_t* d_mask, const uint8_t* d_in_classed, int32_t* d_labels, uint8_t* d_is_core,
+                  uint8_t* d_is_classed, int32_t* cf_out, int64_t* dist_evals);

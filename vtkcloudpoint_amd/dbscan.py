@@ -69,14 +69,16 @@ class DBImproved:
 
 
 class DB:
-    """BaseClass/DB.cs:9-116.  The class is dead in the reference (its only use is commented out at
-    FrmMain.cs:38); its metric is the signed sum dx+dy (:21), an asymmetric relation with no order-free
-    form.  The surface is kept for source compatibility; dbscan is not built for the GPU."""
+    """BaseClass/DB.cs:9-116, the v1.0 class (dead in the reference: its only use is commented out at FrmMain.cs:38).
+    Signed metric dx + dy on (X, Y) (:21), ifShown filter (:40,:63,:98), cluster ids from 1.  dbscan runs on the GPU
+    (csrc/dbdead.hip, the 1-D structure of the signed relation); isKeyPoint / expandCluster stay host-side statics
+    with the C#'s own control flow, as the class exposes them."""
     iritatorNum = 0
 
-    def __init__(self):
+    def __init__(self, ctx=None):
         self.clusterAmount = 0
         self.pointsAmount = 0
+        self._ctx = ctx
 
     @staticmethod
     def getDisP(p1, p2):
@@ -95,8 +97,41 @@ class DB:
 
     @staticmethod
     def expandCluster(p, nei, c, e, minPts, lst):
-        raise NotSupportedError("DB.expandCluster: dead v1.0 class (FrmMain.cs:38); use DBImproved")
+        """DB.cs:57-91, statement by statement (host-side; the never-matching boxed-reference dedupe scan :72-84 is
+        dropped: it only costs time)."""
+        p.clusterId = c
+        t = 0
+        while t < len(nei):
+            dpp = lst[nei[t]]
+            t += 1
+            if not dpp.ifShown:
+                continue
+            if not dpp.isClassed:
+                dpp.isClassed = True
+                tmp = DB.isKeyPoint(lst, dpp, e, minPts)
+                if len(tmp) >= minPts:
+                    nei.extend(tmp)
+            dpp.clusterId = c
 
     def dbscan(self, lst, e, minPts):
-        raise NotSupportedError("DB.dbscan: dead v1.0 class (FrmMain.cs:38, BaseClass/DB.cs:21 signed metric); "
-                                "use DBImproved")
+        """DB.cs:92-115: mutates clusterId / isClassed / isKeyPoint of the shown points of `lst`."""
+        n = len(lst)
+        if n == 0:
+            self.clusterAmount = 0
+            return
+        ctx = self._ctx or default_context()
+        shown = np.fromiter((1 if p.ifShown else 0 for p in lst), np.uint8, n)
+        classed = np.fromiter((1 if p.isClassed else 0 for p in lst), np.uint8, n)
+        labels = np.fromiter((p.clusterId for p in lst), np.int32, n)
+        r = ctx.dbscan(xyz_array(lst)[:, :2].copy(), float(e), int(minPts), _native.SIGNED_SUM_2D, 0, classed, labels,
+                       in_mask=shown)
+        lab, core, cls = r["labels"], r["is_core"], r["is_classed"]
+        for i, p in enumerate(lst):
+            p.clusterId = int(lab[i])
+            if cls[i]:
+                p.isClassed = True
+            if core[i]:
+                p.isKeyPoint = True
+        self.pointsAmount += int(shown.sum())       # :98-101
+        self.clusterAmount = r["cf"]                # :113
+        DB.iritatorNum += r["evals"]

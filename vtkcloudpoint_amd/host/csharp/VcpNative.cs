@@ -2,6 +2,8 @@
 // in vtkPointCloud/BaseClass/.  NOT COMPILED IN THIS REPO'S IMAGE (no dotnet/mono/csc here): kept as the
 // reference-side binding a maintainer adds; the executable mirrors are ../cpp/vcp_host.hpp and the Python
 // package.  Target: .NET Framework 3.5+ (blittable arrays are pinned by the marshaller, no copies).
+// The library is 64-bit only (ROCm) and exports cdecl: build the host AnyCPU/x64, not the reference project's default
+// x86 (vtkPointCloud.csproj:61,71) -- every DllImport names the convention, and Ctx refuses a 32-bit process.
 using System;
 using System.Runtime.InteropServices;
 
@@ -14,85 +16,102 @@ namespace vtkPointCloud
         public const int VCP_L1_2D = 0, VCP_L2_2D = 1, VCP_L2_3D = 2, VCP_SIGNED_SUM_2D = 3;
         public const int VCP_STOP_SSE_DELTA = 0, VCP_STOP_RMSE = 1;
 
-        [DllImport(Lib)] public static extern int vcp_create(int device_id, out IntPtr ctx);
-        [DllImport(Lib)] public static extern void vcp_destroy(IntPtr ctx);
-        [DllImport(Lib)] public static extern IntPtr vcp_last_error(IntPtr ctx);
-        [DllImport(Lib)] public static extern int vcp_release_workspace(IntPtr ctx);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_create(int device_id, out IntPtr ctx);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern void vcp_destroy(IntPtr ctx);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern IntPtr vcp_last_error(IntPtr ctx);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_release_workspace(IntPtr ctx);
 
-        [DllImport(Lib)] public static extern int vcp_dbscan(IntPtr ctx, double[] coords, long n, int dim, int metric,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_dbscan(IntPtr ctx, double[] coords, long n, int dim, int metric,
             double eps, int min_pts, int cf_in, byte[] in_mask, byte[] in_classed, int[] labels, byte[] is_core,
             byte[] is_classed, out int cf_out, out long dist_evals);
 
-        [DllImport(Lib)] public static extern int vcp_dbscan_blocks(IntPtr ctx, double[] motor, long n, double eps,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_dbscan_blocks(IntPtr ctx, double[] motor, long n, double eps,
             int min_pts, int pts_in_cell, int small_max, int[] labels, int[] block_of, long[] merge_order, out long m_out,
             out int rows, out int cols, out int kept, out int del_sum, out int cluster_amount, out long dist_evals);
 
-        [DllImport(Lib)] public static extern int vcp_centroids(IntPtr ctx, double[] xyz, double[] motor, int[] labels,
+        // MainForm.getClusterFromList (FrmMain.cs:1136-1213): partition on (X, Y), DBImproved on motor
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_dbscan_blocks_keyed(IntPtr ctx, double[] key_xy,
+            double[] motor, long n, double eps, int min_pts, int pts_in_cell, int small_max, int[] labels, int[] block_of,
+            long[] merge_order, out long m_out, out int rows, out int cols, out int kept, out int del_sum,
+            out int cluster_amount, out long dist_evals);
+
+        // Tools.getFixedPtsCentroid (Tools.cs:78-111)
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_centroids_weighted(IntPtr ctx, double[] xyz,
+            int[] group, int[] cluster_id, int[] pts_count, long n, int K, int ignore_duplication, double[] c3,
+            long[] inside_num);
+
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_centroids(IntPtr ctx, double[] xyz, double[] motor, int[] labels,
             long n, int K, double[] c3, double[] c2, long[] counts);
 
-        [DllImport(Lib)] public static extern int vcp_merge_centroids(IntPtr ctx, double[] cxy, int[] ids, int K,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_merge_centroids(IntPtr ctx, double[] cxy, int[] ids, int K,
             double thr, int[] map_to, out int merge_count);
 
-        [DllImport(Lib)] public static extern int vcp_icp(IntPtr ctx, double[] model, long nm, double[] data, long nd,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_icp(IntPtr ctx, double[] model, long nm, double[] data, long nd,
             double tol, int max_iter, int stop_rule, double[] R, double[] T, out double sse, out double rmse, out int iters);
 
-        [DllImport(Lib)] public static extern int vcp_match(IntPtr ctx, double[] centers, int K, double[] truths, int T,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_match(IntPtr ctx, double[] centers, int K, double[] truths, int T,
             double[] M, double max_dist, double[] matched_xyz, byte[] is_matched, int[] nearest, double[] nearest_dist,
             out int count_matched);
 
-        [DllImport(Lib)] public static extern int vcp_refresh_by_dictionary(IntPtr ctx, double[] xyz, double[] motor,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_refresh_by_dictionary(IntPtr ctx, double[] xyz, double[] motor,
             int[] labels, long n, int K, int[] map_by_id, out int new_k, double[] c3, double[] c2, long[] counts);
 
-        [DllImport(Lib)] public static extern int vcp_icp_sums(IntPtr ctx, double[] model, long nm, double[] data, long nd,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_icp_sums(IntPtr ctx, double[] model, long nm, double[] data, long nd,
             double[] R, double[] T, double[] sums, int[] nn);
 
         // MainForm.ICP() (FrmMain.cs:841-907): the knobs it sets on vtkIterativeClosestPointTransform
-        [DllImport(Lib)] public static extern int vcp_icp_vtklike(IntPtr ctx, double[] source, long ns, double[] target,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_icp_vtklike(IntPtr ctx, double[] source, long ns, double[] target,
             long nt, int max_iter, int max_landmarks, int start_by_matching_centroids, double[] M, out double mean_dist,
             out int iters);
 
         // Tools.getCircles / Geometry.FindMinimalBoundingCircle (Tools.cs:394-409, Geometry.cs:247-319)
-        [DllImport(Lib)] public static extern int vcp_mcc(IntPtr ctx, double[] xy, int[] labels, long[] order, long m, long n,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_mcc(IntPtr ctx, double[] xy, int[] labels, long[] order, long m, long n,
             int K, double[] centers, double[] radius, byte[] valid, int[] hull_n);
 
         // per-row work of MainForm.AddFolder (FrmMain.cs:1011-1090)
-        [DllImport(Lib)] public static extern int vcp_import_convert(IntPtr ctx, double[] rows, long n, double x_angle,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_import_convert(IntPtr ctx, double[] rows, long n, double x_angle,
             double y_angle, int xdir, int ydir, int dedupe, double[] xyz, byte[] state, out long kept, out long duplicates);
 
         // query of MainForm.refreshClusList (FrmMain.cs:3452-3456)
-        [DllImport(Lib)] public static extern int vcp_assign_truths(IntPtr ctx, double[] motor, long n, double[] truths_xy,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_assign_truths(IntPtr ctx, double[] motor, long n, double[] truths_xy,
             int[] truth_ids, int T, double radius, int[] ids, out long outliers);
 
         // ---- device-resident forms (IntPtr = device address): for hosts that keep the cloud on the GPU between
         // calls, and for the multi-GPU drivers (one process and one context per GPU) ----
-        [DllImport(Lib)] public static extern int vcp_dev_alloc(IntPtr ctx, ulong bytes, out IntPtr dptr);
-        [DllImport(Lib)] public static extern int vcp_dev_free(IntPtr ctx, IntPtr dptr);
-        [DllImport(Lib)] public static extern int vcp_h2d(IntPtr ctx, IntPtr dst_dev, double[] src_host, ulong bytes);
-        [DllImport(Lib)] public static extern int vcp_d2h(IntPtr ctx, int[] dst_host, IntPtr src_dev, ulong bytes);
-        [DllImport(Lib)] public static extern int vcp_dbscan_dev(IntPtr ctx, IntPtr d_coords, long n, int dim, int metric,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_dev_alloc(IntPtr ctx, ulong bytes, out IntPtr dptr);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_dev_free(IntPtr ctx, IntPtr dptr);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_h2d(IntPtr ctx, IntPtr dst_dev, double[] src_host, ulong bytes);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_d2h(IntPtr ctx, int[] dst_host, IntPtr src_dev, ulong bytes);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_dbscan_dev(IntPtr ctx, IntPtr d_coords, long n, int dim, int metric,
             double eps, int min_pts, int cf_in, IntPtr d_in_classed, IntPtr d_labels, IntPtr d_is_core, IntPtr d_is_classed,
             out int cf_out, out long dist_evals);
-        [DllImport(Lib)] public static extern int vcp_centroids_dev(IntPtr ctx, IntPtr d_xyz, IntPtr d_motor, IntPtr d_labels,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_centroids_dev(IntPtr ctx, IntPtr d_xyz, IntPtr d_motor, IntPtr d_labels,
             long n, int K, IntPtr d_c3, IntPtr d_c2, IntPtr d_counts);
-        [DllImport(Lib)] public static extern int vcp_icp_dev(IntPtr ctx, IntPtr d_model, long nm, IntPtr d_data, long nd,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_icp_dev(IntPtr ctx, IntPtr d_model, long nm, IntPtr d_data, long nd,
             double tol, int max_iter, int stop_rule, double[] R, double[] T, out double sse, out double rmse, out int iters);
         // block pipeline in stages (per-block step sharded over GPUs, distributed.py: sharded_blocks)
-        [DllImport(Lib)] public static extern int vcp_blocks_begin(IntPtr ctx, double[] motor, long n, double eps, int min_pts,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_blocks_begin(IntPtr ctx, double[] motor, long n, double eps, int min_pts,
             int pts_in_cell, int small_max, out int rows, out int cols, out long nblocks, out long m);
-        [DllImport(Lib)] public static extern int vcp_blocks_begin_dev(IntPtr ctx, IntPtr d_motor, long n, double eps,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_blocks_begin_dev(IntPtr ctx, IntPtr d_motor, long n, double eps,
             int min_pts, int pts_in_cell, int small_max, out int rows, out int cols, out long nblocks, out long m);
-        [DllImport(Lib)] public static extern int vcp_blocks_share(IntPtr ctx, int rank, int world, out int block_lo,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_blocks_begin_keyed(IntPtr ctx, double[] key_xy,
+            double[] motor, long n, double eps, int min_pts, int pts_in_cell, int small_max, out int rows, out int cols,
+            out long nblocks, out long m);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_blocks_begin_keyed_dev(IntPtr ctx, IntPtr d_key_xy,
+            IntPtr d_motor, long n, double eps, int min_pts, int pts_in_cell, int small_max, out int rows, out int cols,
+            out long nblocks, out long m);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_blocks_share(IntPtr ctx, int rank, int world, out int block_lo,
             out int block_hi, out long pos_lo, out long pos_hi);
-        [DllImport(Lib)] public static extern int vcp_blocks_cluster_dev(IntPtr ctx, int block_lo, int block_hi, IntPtr d_local,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_blocks_cluster_dev(IntPtr ctx, int block_lo, int block_hi, IntPtr d_local,
             out long evals);
-        [DllImport(Lib)] public static extern int vcp_blocks_finish_dev(IntPtr ctx, IntPtr d_local, long evals_blocks,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_blocks_finish_dev(IntPtr ctx, IntPtr d_local, long evals_blocks,
             IntPtr d_labels, IntPtr d_block_of, IntPtr d_merge_order, out long m_out, out int kept, out int del_sum,
             out int cluster_amount, out long dist_evals);
         // one DBImproved.dbscan spread over several GPUs (distributed.py: exact_slabs)
-        [DllImport(Lib)] public static extern int vcp_slab_begin(IntPtr ctx, IntPtr d_coords, long n, int dim, int metric,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_slab_begin(IntPtr ctx, IntPtr d_coords, long n, int dim, int metric,
             double eps, int min_pts, IntPtr d_noexpand, IntPtr d_ord, IntPtr d_rep, IntPtr d_is_core, out long n_comp);
-        [DllImport(Lib)] public static extern int vcp_slab_comps(IntPtr ctx, uint[] comp_rep);
-        [DllImport(Lib)] public static extern int vcp_slab_finish(IntPtr ctx, uint[] map_rep, uint[] map_k, long n_tab,
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_slab_comps(IntPtr ctx, uint[] comp_rep);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_slab_finish(IntPtr ctx, uint[] map_rep, uint[] map_k, long n_tab,
             int[] tab_gid, uint[] tab_seed, uint own_lo, uint own_count, IntPtr d_labels, IntPtr d_is_classed, out long twice);
 
         // one context per thread: StartCode runs on ThreadPool threads (FrmMain.cs:1358)
@@ -103,6 +122,7 @@ namespace vtkPointCloud
             {
                 if (tlsCtx == IntPtr.Zero)
                 {
+                    if (IntPtr.Size != 8) throw new InvalidOperationException("libvcp is 64-bit only: build the host x64 / AnyCPU without Prefer32Bit");
                     int rc = vcp_create(0, out tlsCtx);
                     if (rc != 0) throw new InvalidOperationException("vcp_create: " + Marshal.PtrToStringAnsi(vcp_last_error(IntPtr.Zero)));
                 }

@@ -443,12 +443,58 @@ __global__ __launch_bounds__(TPB) void k_wl_fill(const uint8_t* __restrict__ fla
 }
 
 // ---- core flags (region query with early exit at min_pts) ---------------------------------------
+// Neighbour lists.  While counting, every point also RECORDS the positions of the first NB = min_pts - 1 neighbours it
+// meets (itself excluded): a point that stays below min_pts has then recorded its whole neighbourhood, so the border
+// rule needs no second search (k_border_list), and an expanding point can take its first tree link from the list
+// (k_union_init_list) instead of searching again.  Lists are staged per lane in LDS (k-major: lane t's k-th entry at
+// [k * TPB + t], conflict free), then COMPACTED per workgroup: the lists of the 256 positions of a block are packed
+// back to back at the front of the block's fixed slot of NB * 256 words, so they are stored as full lines (sparse
+// per-point slots were measured 0.2 ms slower: partial-line stores).  off[p] = start of p's list inside its block's
+// slot (16 bits), the count sits in the upper four bits of the point's flag byte.  NB == 0 switches the recording off
+// (min_pts outside 2..16).
+struct NbrOut {
+  uint32_t* nbr;     // [nblocks * NB * TPB]
+  uint16_t* off;     // [n]
+  int NB;            // 0..15
+};
+
+__device__ __forceinline__ const uint32_t* nbr_list(const NbrOut& no, uint32_t p) {
+  return no.nbr + (size_t)(p / TPB) * (size_t)(no.NB * TPB) + no.off[p];
+}
+
+// lnb: the lanes' staged lists; lout: NB * TPB words of LDS the caller no longer needs.  blk = block of positions.
+__device__ __forceinline__ void nbr_flush(const NbrOut& no, const uint32_t* lnb, uint32_t* lout, int nrec, int64_t blk,
+                                          int64_t p, bool live) {
+  if (no.NB == 0) return;
+  __shared__ uint32_t wtot[TPB / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t inc = (uint32_t)nrec;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) wtot[w] = inc;
+  __syncthreads();  // also: every lane is done with the memory behind lout
+  uint32_t pre = inc - (uint32_t)nrec, total = 0;
+  for (int k = 0; k < TPB / 64; k++) {
+    if (k < w) pre += wtot[k];
+    total += wtot[k];
+  }
+  for (int k = 0; k < nrec; k++) lout[pre + k] = lnb[k * TPB + threadIdx.x];
+  if (live) no.off[p] = (uint16_t)pre;
+  __syncthreads();
+  uint32_t* dst = no.nbr + (size_t)blk * (size_t)(no.NB * TPB);
+  for (uint32_t k = threadIdx.x; k < total; k += TPB) dst[k] = lout[k];
+}
+
 template <int GD, int METRIC, bool GROUPED>
 __global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted, GridP g, double thr, int min_pts,
                                              const uint32_t* __restrict__ cellstart,
                                              const int32_t* __restrict__ sgroup, uint8_t* __restrict__ flags,
                                              uint32_t* __restrict__ parent, uint32_t* __restrict__ minord,
-                                             uint32_t* __restrict__ blkE, uint32_t* __restrict__ blkB) {
+                                             uint32_t* __restrict__ blkE, uint32_t* __restrict__ blkB, NbrOut no) {
+  extern __shared__ uint32_t lnb[];  // [NB * TPB] staged lists, then [NB * TPB] for their compaction
   const uint32_t nin = cellstart[g.ncells];
   const int64_t blk = xcd_block(gridDim.x);
   int64_t p = blk * TPB + threadIdx.x;
@@ -461,7 +507,8 @@ __global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted,
   }
   constexpr int UNR = GD == 3 ? VCP_UNR3 : VCP_UNR2;
   const int32_t myg = (GROUPED && live) ? sgroup[p] : 0;
-  int cnt = 0;
+  int cnt = 0, nrec = 0;
+  const int NB = no.NB;
   if (live) for_rows<GD>(cc, g, cellstart, [&](uint32_t s, uint32_t e) {
     // batches of UNR candidates: UNR independent loads in flight per lane (the loop is latency bound), the
     // early exit is checked once per batch
@@ -479,6 +526,7 @@ __global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted,
         bool ok = (j + u < e) && within<METRIC>(q, r[u], thr);
         if (GROUPED) ok = ok && gj[u] == myg;
         cnt += ok ? 1 : 0;
+        if (ok && nrec < NB && j + u != (uint32_t)p) lnb[(nrec++) * TPB + threadIdx.x] = j + u;
       }
       if (cnt >= min_pts) return false;
     }
@@ -500,12 +548,13 @@ __global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted,
   }
   if (isB) fl |= F_BCAND;
   if (live) {
-    flags[p] = fl;
+    flags[p] = fl | (uint8_t)(nrec << 4);
     // union-find start: parent[p] = p for expanding points, NONE for all others, so that the component kernels
     // can tell "expanding, and in which tree" from ONE 4-byte load per candidate
     parent[p] = isE ? (uint32_t)p : NONE;
     minord[p] = NONE;
   }
+  nbr_flush(no, lnb, lnb + no.NB * TPB, nrec, blk, p, live);
   wl_count(isE, isB, (uint32_t)blk, blkE, blkB);
 }
 
@@ -572,11 +621,60 @@ __device__ __forceinline__ void tile_load(RowTile& t, const double* __restrict__
   __syncthreads();
 }
 
+// LDS-free list recording for k_core_lds: the lane's hits are bit masks (hm) over its first 32 candidates per row, so
+// the count is a popcount, the block-wide compaction offset a scan of the counts, and the positions are read off the
+// masks straight into the compacted image -- which reuses the row tile once every lane is done with it.  A lane with a
+// hit beyond the masks that stays below min_pts (`rescan`) walks its rows again in global memory: rare.
+template <int METRIC>
+__device__ __forceinline__ void nbr_flush_masks(const NbrOut& no, uint32_t* lout, const uint32_t* hm, const uint32_t* rs,
+                                                const uint32_t* re, bool rescan, int nrec, const double* q, double thr,
+                                                const double* __restrict__ sorted, int64_t blk, int64_t p, bool live) {
+  if (no.NB == 0) return;
+  __shared__ uint32_t wtot[TPB / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t inc = (uint32_t)nrec;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) wtot[w] = inc;
+  __syncthreads();  // also: every lane is done with the tile behind lout
+  uint32_t pre = inc - (uint32_t)nrec, total = 0;
+  for (int k = 0; k < TPB / 64; k++) {
+    if (k < w) pre += wtot[k];
+    total += wtot[k];
+  }
+  if (live) no.off[p] = (uint16_t)pre;
+  int k = 0;
+  if (rescan) {
+    for (int r = 0; r < 3; r++)
+      for (uint32_t j = rs[r]; j < re[r] && k < nrec; j++) {
+        double rr[3];
+        load_pt<2>(sorted, j, rr);
+        if (j != (uint32_t)p && within<METRIC>(q, rr, thr)) lout[pre + (k++)] = j;
+      }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      uint32_t m = hm[r];
+      while (m != 0u && k < nrec) {
+        const uint32_t pos = rs[r] + (uint32_t)(__ffs((int)m) - 1);
+        m &= m - 1u;
+        if (pos != (uint32_t)p) lout[pre + (k++)] = pos;
+      }
+    }
+  }
+  __syncthreads();
+  uint32_t* dst = no.nbr + (size_t)blk * (size_t)(no.NB * TPB);
+  for (uint32_t i = threadIdx.x; i < total; i += TPB) dst[i] = lout[i];
+}
+
 template <int METRIC>
 __global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sorted, GridP g, double thr, int min_pts,
                                                  const uint32_t* __restrict__ cellstart, uint8_t* __restrict__ flags,
                                                  uint32_t* __restrict__ parent, uint32_t* __restrict__ minord,
-                                                 uint32_t* __restrict__ blkE, uint32_t* __restrict__ blkB) {
+                                                 uint32_t* __restrict__ blkE, uint32_t* __restrict__ blkB, NbrOut no) {
   __shared__ RowTile t;
   const uint32_t nin = cellstart[g.ncells];
   const int64_t blk = xcd_block(gridDim.x);
@@ -591,7 +689,12 @@ __global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sor
   uint32_t rs[3], re[3];
   const bool fits = tile_bounds<RowTile, TILE_CAP>(t, live, cc, g, cellstart, rs, re);
   constexpr int UNR = VCP_UNR2;
+  static_assert(UNR == 4, "hit nibbles");
   int cnt = 0;
+  // per row a bit mask of which of the lane's first 32 candidates were hits (two extra VALU operations per candidate;
+  // writing positions to LDS as they were found cost seven, plus the LDS that held them: 0.2 ms on this VALU-bound
+  // kernel); ovf = hits beyond the masks
+  uint32_t hm[3] = {0u, 0u, 0u}, ovf = 0u;
   if (fits) {
     tile_load(t, sorted);
     if (live) {
@@ -599,16 +702,21 @@ __global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sor
       for (int r = 0; r < 3; r++) {
         if (cnt >= min_pts || rs[r] >= re[r]) continue;
         const uint32_t lo = t.lo[r];
-        const uint32_t e = re[r] - lo;
-        for (uint32_t j = rs[r] - lo; j < e; j += UNR) {
+        const uint32_t e = re[r] - lo, a = rs[r] - lo;
+        for (uint32_t j = a; j < e; j += UNR) {
           double2 c[UNR];
 #pragma unroll
           for (int u = 0; u < UNR; u++) c[u] = t.pt[r][min(j + u, e - 1)];
+          uint32_t nib = 0;
 #pragma unroll
           for (int u = 0; u < UNR; u++) {
             const double rr[3] = {c[u].x, c[u].y, 0.0};
-            cnt += ((j + u < e) && within<METRIC>(q, rr, thr)) ? 1 : 0;
+            nib |= ((j + u < e) && within<METRIC>(q, rr, thr)) ? (1u << u) : 0u;
           }
+          cnt += __popc(nib);
+          const uint32_t sh = j - a;
+          hm[r] |= sh < 32u ? nib << sh : 0u;
+          ovf |= sh < 32u ? 0u : nib;
           if (cnt >= min_pts) break;
         }
       }
@@ -619,11 +727,30 @@ __global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sor
         double rr[UNR][3];
 #pragma unroll
         for (int u = 0; u < UNR; u++) load_pt<2>(sorted, min(j + u, re[r] - 1), rr[u]);
+        uint32_t nib = 0;
 #pragma unroll
-        for (int u = 0; u < UNR; u++) cnt += ((j + u < re[r]) && within<METRIC>(q, rr[u], thr)) ? 1 : 0;
+        for (int u = 0; u < UNR; u++) nib |= ((j + u < re[r]) && within<METRIC>(q, rr[u], thr)) ? (1u << u) : 0u;
+        cnt += __popc(nib);
+        const uint32_t sh = j - rs[r];
+        hm[r] |= sh < 32u ? nib << sh : 0u;
+        ovf |= sh < 32u ? 0u : nib;
         if (cnt >= min_pts) break;
       }
     }
+  }
+  // recorded neighbours: a lane below min_pts with hits beyond the masks re-scans (its count is exact: cnt - itself);
+  // everybody else takes what the masks hold, itself excluded
+  const bool rescan = live && no.NB > 0 && ovf != 0u && cnt < min_pts;
+  int nrec = 0;
+  if (live && no.NB > 0) {
+    if (rescan) {
+      nrec = max(cnt - 1, 0);
+    } else {
+      nrec = __popc(hm[0]) + __popc(hm[1]) + __popc(hm[2]);
+      const uint32_t sb = (uint32_t)p - rs[1];  // the point itself sits in its own row (a NaN point has no hit at all)
+      if (rs[1] < re[1] && sb < 32u && ((hm[1] >> sb) & 1u)) nrec--;
+    }
+    nrec = min(nrec, no.NB);
   }
   uint8_t fl = live ? flags[p] : 0;
   bool isE = false, isB = false;
@@ -641,12 +768,14 @@ __global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sor
   }
   if (isB) fl |= F_BCAND;
   if (live) {
-    flags[p] = fl;
+    flags[p] = fl | (uint8_t)(nrec << 4);
     // union-find start: parent[p] = p for expanding points, NONE for all others, so that the component kernels
     // can tell "expanding, and in which tree" from ONE 4-byte load per candidate
     parent[p] = isE ? (uint32_t)p : NONE;
     minord[p] = NONE;
   }
+  nbr_flush_masks<METRIC>(no, reinterpret_cast<uint32_t*>(&t.pt[0][0]), hm, rs, re, rescan, nrec, q, thr, sorted, blk, p,
+                          live);
   wl_count(isE, isB, (uint32_t)blk, blkE, blkB);
 }
 
@@ -734,6 +863,24 @@ __global__ __launch_bounds__(TPB) void k_union_init(const double* __restrict__ s
     return true;
   });
   if (first != me) parent[me] = first;
+}
+
+// Phase 1 from the recorded lists (no search): the first recorded neighbour that is expanding and sits at a smaller
+// position.  An expanding point whose smaller expanding neighbours all lie beyond its NB recorded ones stays a root for
+// now; phase 3 scans every edge anyway.
+__global__ __launch_bounds__(TPB) void k_union_init_list(const uint8_t* __restrict__ flags, uint32_t* __restrict__ parent,
+                                                        NbrOut no, WorkList wlE) {
+  const uint32_t p = wl_fetch(wlE);
+  if (p == NONE) return;
+  const int nrec = flags[p] >> 4;
+  const uint32_t* li = nbr_list(no, p);
+  for (int k = 0; k < nrec; k++) {
+    const uint32_t j = li[k];
+    if (j < p && (flags[j] & F_EXPAND)) {
+      parent[p] = j;
+      return;
+    }
+  }
 }
 
 // Phase 2: flatten the phase-1 forest (no atomics; a racing reader sees an older or a newer ancestor)
@@ -947,6 +1094,21 @@ __global__ __launch_bounds__(TPB) void k_rootk(const uint32_t* __restrict__ pare
   }
 }
 
+// border points the C# queried twice: one atomic per WORKGROUP, spread over 32 slots (counters[36..68)).  One atomic
+// per wave on a single word cost 0.2 ms here: about half of 53 k waves hit it, and same-address atomics serialise at
+// ~11 ns each.
+__device__ __forceinline__ void twice_add(unsigned twice, unsigned long long* __restrict__ counters) {
+  __shared__ unsigned tw[TPB / 64];
+  const unsigned long long m2 = __ballot(twice);
+  if ((threadIdx.x & 63) == 0) tw[threadIdx.x >> 6] = (unsigned)__popcll(m2);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned t = 0;
+    for (int k = 0; k < TPB / 64; k++) t += tw[k];
+    if (t) atomicAdd(&counters[36 + (blockIdx.x & 31)], (unsigned long long)t);
+  }
+}
+
 // ---- border rule: labk[p] = 1 + seed rank of the final cluster ------------------------------------
 // twice[...] counts border points the C# main loop had already queried before their first cluster's
 // seed came up (BaseClass/DBImproved.cs:93-104 then :63-67)
@@ -1005,10 +1167,38 @@ __global__ __launch_bounds__(TPB) void k_border(const double* __restrict__ sorte
     }
     labk[p] = (out << 2) | ((fl & F_CORE) ? 1u : 0u) | ((fl & F_CLASSED) ? 2u : 0u);
   }
-  if (!GROUPED) {
-    unsigned long long m2 = __ballot(twice);
-    if ((threadIdx.x & 63) == 0 && m2) atomicAdd(&counters[1], (unsigned long long)__popcll(m2));
+  if (!GROUPED) twice_add(twice, counters);
+}
+
+// The border rule from the recorded lists: a point below min_pts has recorded ALL its neighbours, so the largest /
+// smallest adjacent cluster comes from <= NB rank words, no cell walk, no coordinates.  (Classed core points -- only
+// possible with an isClassed input -- exit the count early and have incomplete lists: those calls keep k_border.)
+template <bool GROUPED>
+__global__ __launch_bounds__(TPB) void k_border_list(const int32_t* __restrict__ sgroup, const uint8_t* __restrict__ flags,
+                                                    const uint32_t* __restrict__ sord, const uint32_t* __restrict__ rootk,
+                                                    const uint32_t* __restrict__ clseed, uint32_t* __restrict__ labk,
+                                                    unsigned long long* __restrict__ counters,
+                                                    uint32_t* __restrict__ group_twice, NbrOut no, WorkList wlB) {
+  const uint32_t p = wl_fetch(wlB);
+  unsigned twice = 0;
+  if (p != NONE) {
+    const uint8_t fl = flags[p];
+    const int nrec = fl >> 4;
+    uint32_t mx = 0, mnk = NONE;
+    const uint32_t* li = nbr_list(no, p);
+    for (int k = 0; k < nrec; k++) {
+      const uint32_t x = rootk[li[k]];
+      if (x == NONE) continue;
+      mx = max(mx, x + 1u);
+      mnk = min(mnk, x);
+    }
+    if (mx != 0 && sord[p] < clseed[mnk]) {  // nobody is classed on entry in these calls
+      twice = 1;
+      if (GROUPED) atomicAdd(&group_twice[sgroup[p]], 1u);
+    }
+    labk[p] = (mx << 2) | ((fl & F_CORE) ? 1u : 0u) | ((fl & F_CLASSED) ? 2u : 0u);
   }
+  if (!GROUPED) twice_add(twice, counters);
 }
 
 // labk of every position the border list does not cover: expanding points take their component's rank,
@@ -1292,7 +1482,7 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   // 1. bounds over finite coordinates
   vcp_phase(ctx, "bounds");
   const int rb = (int)vcp_blocks(n, TPB, 1024);
-  VCP_TRY(vcp_ensure(ctx, ctx->b_misc, (size_t)(rb * 8 + 64) * sizeof(double)));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_misc, (size_t)(rb * 8 + 96) * sizeof(double)));
   double* d_part = ctx->b_misc.as<double>();
   double* d_bounds = d_part + (size_t)rb * 8;
   hipLaunchKernelGGL((k_bounds<GD, GROUPED>), dim3(rb), dim3(TPB), 0, st, d_coords, n, stride, d_group, glo, ghi, d_part);
@@ -1528,12 +1718,24 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   wlE.perblk = wlB.perblk = list_perblk(n);
   VCP_HIP(ctx, hipMemsetAsync(blkE, 0, (size_t)(nb + 2) * 2 * 4, st));
   const unsigned nbl = 8u * LCHUNK * wlE.perblk;  // list kernels: see wl_fetch
+  // neighbour lists (see NbrOut): off when the caller passes isClassed (classed core points need the full search), for
+  // staged calls (vcp_slab_finish searches again with the resolved ids) and for min_pts outside 2..16
+  static const bool lists_off = getenv("VCP_NO_LISTS") != nullptr;
+  NbrOut no{nullptr, nullptr, 0};
+  if (!lists_off && !d_in_classed && !(ext && ext->slab) && min_pts >= 2 && min_pts <= 16) {
+    no.NB = min_pts - 1;
+    VCP_TRY(vcp_ensure(ctx, ctx->b_nbr, (size_t)no.NB * (size_t)nb * TPB * 4));
+    VCP_TRY(vcp_ensure(ctx, ctx->b_nboff, (size_t)nb * TPB * 2));
+    no.nbr = ctx->b_nbr.as<uint32_t>();
+    no.off = ctx->b_nboff.as<uint16_t>();
+  }
+  const size_t lds_nb = (size_t)no.NB * TPB * 4;
   if constexpr (GD == 2 && !GROUPED)
     hipLaunchKernelGGL((k_core_lds<METRIC>), dim3(nb), dim3(TPB), 0, st, sorted, g, thr, min_pts, cellcnt, flags, parent,
-                       minord, blkE, blkB);
+                       minord, blkE, blkB, no);
   else
-    hipLaunchKernelGGL((k_core<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 0, st, sorted, g, thr, min_pts, cellcnt, sgroup,
-                       flags, parent, minord, blkE, blkB);
+    hipLaunchKernelGGL((k_core<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 2 * lds_nb, st, sorted, g, thr, min_pts, cellcnt,
+                       sgroup, flags, parent, minord, blkE, blkB, no);
   VCP_TRY(vcp_exclusive_scan_u32(ctx, blkE, blkE, (int64_t)nb + 1, nullptr));
   VCP_TRY(vcp_exclusive_scan_u32(ctx, blkB, blkB, (int64_t)nb + 1, nullptr));
   hipLaunchKernelGGL(k_wl_fill, dim3(nb), dim3(TPB), 0, st, flags, cellcnt, g.ncells, blkE, blkB, wlE.list, wlB.list);
@@ -1541,15 +1743,23 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   // 6. components of the expanding points
   vcp_phase(ctx, "union");
   VCP_HIP(ctx, hipMemsetAsync(seedflag, 0, (size_t)nw * 4, st));
-  VCP_HIP(ctx, hipMemsetAsync(counters, 0, 36 * sizeof(unsigned long long), st));
+  VCP_HIP(ctx, hipMemsetAsync(counters, 0, 68 * sizeof(unsigned long long), st));
   // phases 1-2 pay for their extra search pass in 2-D (3 rows); in 3-D (9 rows) they do not (measured: +28 %)
-  if (GD == 2) {
+  const bool pre = GD == 2 || no.NB > 0;  // with lists the forest costs no search, so it pays in 3-D too
+  if (no.NB > 0) {
+    hipLaunchKernelGGL(k_union_init_list, dim3(nbl), dim3(TPB), 0, st, flags, parent, no, wlE);
+    hipLaunchKernelGGL(k_flatten0, dim3(nb), dim3(TPB), 0, st, parent, flags, cellcnt, g.ncells);
+  } else if (GD == 2) {
     hipLaunchKernelGGL((k_union_init<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup,
                        flags, parent, wlE);
     hipLaunchKernelGGL(k_flatten0, dim3(nb), dim3(TPB), 0, st, parent, flags, cellcnt, g.ncells);
   }
-  hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED, GD == 2>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup,
-                     parent, wlE);
+  if (pre)
+    hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED, true>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup,
+                       parent, wlE);
+  else
+    hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED, false>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup,
+                       parent, wlE);
   vcp_phase(ctx, "flatten_number");
   hipLaunchKernelGGL(k_flatten, dim3(nb), dim3(TPB), 0, st, parent, flags, sord, minord, cellcnt, g.ncells);
   if (!GROUPED && ext && ext->slab) {
@@ -1587,8 +1797,12 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   vcp_phase(ctx, "border");
   if (GROUPED) VCP_HIP(ctx, hipMemsetAsync(ext->d_group_twice, 0, (size_t)G * 4, st));
   hipLaunchKernelGGL(k_labk_rest, dim3(nb), dim3(TPB), 0, st, flags, parent, rootk, labk, cellcnt, g.ncells);
-  hipLaunchKernelGGL((k_border<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup, flags,
-                     parent, sord, rootk, clseed, labk, counters, GROUPED ? ext->d_group_twice : nullptr, wlB, 0u, NONE);
+  if (no.NB > 0)
+    hipLaunchKernelGGL(k_border_list<GROUPED>, dim3(nbl), dim3(TPB), 0, st, sgroup, flags, sord, rootk, clseed, labk, counters,
+                       GROUPED ? ext->d_group_twice : nullptr, no, wlB);
+  else
+    hipLaunchKernelGGL((k_border<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup, flags,
+                       parent, sord, rootk, clseed, labk, counters, GROUPED ? ext->d_group_twice : nullptr, wlB, 0u, NONE);
   if (part_out) {
     GridOutputArgs oa;
     oa.n = n;
@@ -1618,7 +1832,7 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   }
   VCP_HIP(ctx, hipGetLastError());
   unsigned long long* hc = reinterpret_cast<unsigned long long*>(ctx->pinned) + 8;
-  VCP_HIP(ctx, hipMemcpyAsync(hc, counters, 36 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  VCP_HIP(ctx, hipMemcpyAsync(hc, counters, 68 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   VCP_TRY(vcp_phase_finish(ctx));
   VCP_HIP(ctx, hipStreamSynchronize(st));
   const uint32_t K = *reinterpret_cast<uint32_t*>(hc + 2);
@@ -1628,7 +1842,9 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
     for (int k = 0; k < 32; k++) unclassed += hc[4 + k];
   }
   if (cf_out) *cf_out = cf_in + (int32_t)K;
-  if (dist_evals) *dist_evals = GROUPED ? (int64_t)hc[3] : (int64_t)(unclassed + hc[1] + K - hc[0]) * n;
+  unsigned long long twice_total = 0;
+  for (int k = 0; k < 32; k++) twice_total += hc[36 + k];
+  if (dist_evals) *dist_evals = GROUPED ? (int64_t)hc[3] : (int64_t)(unclassed + twice_total + K - hc[0]) * n;
   return VCP_OK;
 }
 
@@ -1661,7 +1877,7 @@ int run_slab_finish(vcp_ctx* ctx, const SlabState& ss, const uint32_t* d_map_rep
   const int rb = (int)vcp_blocks(n, TPB, 1024);
   unsigned long long* counters = reinterpret_cast<unsigned long long*>(ctx->b_misc.as<double>() + (size_t)rb * 8 + 8);
   vcp_phase(ctx, "slab_roots");
-  VCP_HIP(ctx, hipMemsetAsync(counters, 0, 4 * sizeof(unsigned long long), st));
+  VCP_HIP(ctx, hipMemsetAsync(counters, 0, 68 * sizeof(unsigned long long), st));
   hipLaunchKernelGGL(k_slab_rootk, dim3(nb), dim3(TPB), 0, st, parent, flags, minord, cellcnt, g.ncells, d_map_rep, d_map_k,
                      (uint32_t)ss.n_comp, rootk, counters);
   vcp_phase(ctx, "border");
@@ -1672,12 +1888,15 @@ int run_slab_finish(vcp_ctx* ctx, const SlabState& ss, const uint32_t* d_map_rep
   hipLaunchKernelGGL(k_slab_output, dim3(nb), dim3(TPB), 0, st, n, pos, labk, d_tab_gid, d_labels, d_is_classed);
   VCP_HIP(ctx, hipGetLastError());
   unsigned long long* hc = reinterpret_cast<unsigned long long*>(ctx->pinned) + 8;
-  VCP_HIP(ctx, hipMemcpyAsync(hc, counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  VCP_HIP(ctx, hipMemcpyAsync(hc, counters, 68 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   VCP_TRY(vcp_phase_finish(ctx));
   VCP_HIP(ctx, hipStreamSynchronize(st));
   if (hc[0] != 0)
     return vcp_fail(ctx, VCP_ERR_ARG, "%llu local components are missing from the map", hc[0]);
-  if (twice) *twice = (int64_t)hc[1];
+  if (twice) {
+    *twice = 0;
+    for (int k = 0; k < 32; k++) *twice += (int64_t)hc[36 + k];
+  }
   return VCP_OK;
 }
 

@@ -884,11 +884,9 @@ __global__ __launch_bounds__(TPB) void k_union_init_list(const uint8_t* __restri
 }
 
 // Phase 2: flatten the phase-1 forest (no atomics; a racing reader sees an older or a newer ancestor)
-__global__ __launch_bounds__(TPB) void k_flatten0(uint32_t* __restrict__ parent, const uint8_t* __restrict__ flags,
-                                                 const uint32_t* __restrict__ cellstart, uint32_t ncells) {
-  const uint32_t nin = cellstart[ncells];
-  int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
-  if (p >= nin || !(flags[p] & F_EXPAND)) return;
+__global__ __launch_bounds__(TPB) void k_flatten0(uint32_t* __restrict__ parent, WorkList wlE) {
+  const uint32_t p = wl_fetch(wlE);  // expanding points only (a quarter of the positions here)
+  if (p == NONE) return;
   uint32_t r = (uint32_t)p, x = ld_parent_cached(parent, r);
   if (x == r) return;
   while (x != r) {
@@ -927,6 +925,8 @@ __global__ __launch_bounds__(TPB) void k_flatten0(uint32_t* __restrict__ parent,
     q0 = q1 = NONE;                                                \
   } while (0)
 
+// (Staging the parent words of a workgroup's three candidate rows in LDS, as the core count does with coordinates, was
+// measured: 282 us against 258 us -- the per-workgroup range reduction and barriers cost more than the L1 accesses saved.)
 template <int GD, int METRIC, bool GROUPED, bool PRE>
 __global__ __launch_bounds__(TPB) void k_union(const double* __restrict__ sorted, GridP g, double thr,
                                               const uint32_t* __restrict__ cellstart,
@@ -934,19 +934,19 @@ __global__ __launch_bounds__(TPB) void k_union(const double* __restrict__ sorted
                                               WorkList wlE) {
   const uint32_t p = wl_fetch(wlE);
   if (p == NONE) return;
+  constexpr int NR = GD == 3 ? 9 : 3;
+  uint32_t rs[NR], re[NR];
   double q[3];
   int cc[3];
   load_pt<GD>(sorted, p, q);
   cell_of<GD>(q, g, cc);
+  row_bounds<GD>(cc, g, cellstart, rs, re);
   constexpr int UNR = PRE ? VCP_UNRW : (GD == 3 ? VCP_UNR3 : VCP_UNR2);
-  constexpr int NR = GD == 3 ? 9 : 3;
   const int32_t myg = GROUPED ? sgroup[p] : 0;
   const uint32_t me = (uint32_t)p;
   uint32_t rp = parent[me];  // cached root of my tree (flattened by phase 2)
   // q0,q1 = queued edges; a0..a2 = words known to be in my tree
   uint32_t q0 = NONE, q1 = NONE, a0 = NONE, a1 = NONE, a2 = NONE;
-  uint32_t rs[NR], re[NR];
-  row_bounds<GD>(cc, g, cellstart, rs, re);
 #pragma unroll
   for (int r = 0; r < NR; r++) {
     const uint32_t s = rs[r];
@@ -1025,13 +1025,11 @@ __global__ __launch_bounds__(TPB) void k_union(const double* __restrict__ sorted
 
 // flatten + smallest list position per component; lanes of a wave that share a root (the common
 // case inside a blob: the wave covers neighbouring cells) combine before one atomicMin
-__global__ __launch_bounds__(TPB) void k_flatten(uint32_t* __restrict__ parent, const uint8_t* __restrict__ flags,
-                                                const uint32_t* __restrict__ sord, uint32_t* __restrict__ minord,
-                                                const uint32_t* __restrict__ cellstart, uint32_t ncells) {
-  const uint32_t nin = cellstart[ncells];
-  int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
+__global__ __launch_bounds__(TPB) void k_flatten(uint32_t* __restrict__ parent, const uint32_t* __restrict__ sord,
+                                                uint32_t* __restrict__ minord, WorkList wlE) {
+  const uint32_t p = wl_fetch(wlE);
   uint32_t r = NONE, v = NONE;
-  if (p < nin && (flags[p] & F_EXPAND)) {
+  if (p != NONE) {
     r = (uint32_t)p;
     uint32_t x = parent[r];
     while (x != r) {
@@ -1067,27 +1065,22 @@ __global__ __launch_bounds__(TPB) void k_seed_popc(const uint32_t* __restrict__ 
   if (w < nw) cnt[w] = (uint32_t)__popc(bits[w]);
 }
 
-__global__ __launch_bounds__(TPB) void k_seedflag(const uint32_t* __restrict__ parent, const uint8_t* __restrict__ flags,
-                                                 const uint32_t* __restrict__ minord, uint32_t* __restrict__ seedflag,
-                                                 const uint32_t* __restrict__ cellstart, uint32_t ncells) {
-  const uint32_t nin = cellstart[ncells];
-  int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
-  if (p >= nin) return;
-  if ((flags[p] & F_EXPAND) && parent[p] == (uint32_t)p) {
+__global__ __launch_bounds__(TPB) void k_seedflag(const uint32_t* __restrict__ parent, const uint32_t* __restrict__ minord,
+                                                 uint32_t* __restrict__ seedflag, WorkList wlE) {
+  const uint32_t p = wl_fetch(wlE);
+  if (p == NONE) return;
+  if (parent[p] == p) {
     const uint32_t m = minord[p];
     atomicOr(&seedflag[m >> 5], 1u << (m & 31u));
   }
 }
 
-__global__ __launch_bounds__(TPB) void k_rootk(const uint32_t* __restrict__ parent, const uint8_t* __restrict__ flags,
-                                              const uint32_t* __restrict__ minord, const uint32_t* __restrict__ seedbits,
-                                              const uint32_t* __restrict__ seedpref,
-                                              uint32_t* __restrict__ rootk, uint32_t* __restrict__ clseed,
-                                              const uint32_t* __restrict__ cellstart, uint32_t ncells) {
-  const uint32_t nin = cellstart[ncells];
-  int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
-  if (p >= nin) return;
-  if ((flags[p] & F_EXPAND) && parent[p] == (uint32_t)p) {
+__global__ __launch_bounds__(TPB) void k_rootk(const uint32_t* __restrict__ parent, const uint32_t* __restrict__ minord,
+                                              const uint32_t* __restrict__ seedbits, const uint32_t* __restrict__ seedpref,
+                                              uint32_t* __restrict__ rootk, uint32_t* __restrict__ clseed, WorkList wlE) {
+  const uint32_t p = wl_fetch(wlE);
+  if (p == NONE) return;
+  if (parent[p] == p) {
     uint32_t k = seed_rank(seedbits, seedpref, minord[p]);
     rootk[p] = k;
     clseed[k] = minord[p];
@@ -1748,11 +1741,11 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   const bool pre = GD == 2 || no.NB > 0;  // with lists the forest costs no search, so it pays in 3-D too
   if (no.NB > 0) {
     hipLaunchKernelGGL(k_union_init_list, dim3(nbl), dim3(TPB), 0, st, flags, parent, no, wlE);
-    hipLaunchKernelGGL(k_flatten0, dim3(nb), dim3(TPB), 0, st, parent, flags, cellcnt, g.ncells);
+    hipLaunchKernelGGL(k_flatten0, dim3(nbl), dim3(TPB), 0, st, parent, wlE);
   } else if (GD == 2) {
     hipLaunchKernelGGL((k_union_init<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup,
                        flags, parent, wlE);
-    hipLaunchKernelGGL(k_flatten0, dim3(nb), dim3(TPB), 0, st, parent, flags, cellcnt, g.ncells);
+    hipLaunchKernelGGL(k_flatten0, dim3(nbl), dim3(TPB), 0, st, parent, wlE);
   }
   if (pre)
     hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED, true>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup,
@@ -1761,7 +1754,7 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
     hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED, false>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup,
                        parent, wlE);
   vcp_phase(ctx, "flatten_number");
-  hipLaunchKernelGGL(k_flatten, dim3(nb), dim3(TPB), 0, st, parent, flags, sord, minord, cellcnt, g.ncells);
+  hipLaunchKernelGGL(k_flatten, dim3(nbl), dim3(TPB), 0, st, parent, sord, minord, wlE);
   if (!GROUPED && ext && ext->slab) {
     // staged call: hand the local components to the caller and keep the grid state for vcp_slab_finish
     vcp_phase(ctx, "slab_components");
@@ -1787,11 +1780,10 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
     if (cf_out) *cf_out = (int32_t)hn[0];
     return VCP_OK;
   }
-  hipLaunchKernelGGL(k_seedflag, dim3(nb), dim3(TPB), 0, st, parent, flags, minord, seedflag, cellcnt, g.ncells);
+  hipLaunchKernelGGL(k_seedflag, dim3(nbl), dim3(TPB), 0, st, parent, minord, seedflag, wlE);
   hipLaunchKernelGGL(k_seed_popc, dim3(vcp_blocks(nw, TPB)), dim3(TPB), 0, st, seedflag, nw, seedpref);
   VCP_TRY(vcp_exclusive_scan_u32(ctx, seedpref, seedpref, nw, d_total));
-  hipLaunchKernelGGL(k_rootk, dim3(nb), dim3(TPB), 0, st, parent, flags, minord, seedflag, seedpref, rootk, clseed, cellcnt,
-                     g.ncells);
+  hipLaunchKernelGGL(k_rootk, dim3(nbl), dim3(TPB), 0, st, parent, minord, seedflag, seedpref, rootk, clseed, wlE);
 
   // 7. border rule, then outputs in caller order
   vcp_phase(ctx, "border");

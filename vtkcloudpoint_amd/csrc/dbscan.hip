@@ -79,6 +79,33 @@ __device__ __forceinline__ bool within(const double* a, const double* b, double 
   }
 }
 
+// binary32 value of the distance form between two screening copies (relative coordinates): what Screen.lo / hi bound
+template <int METRIC>
+__device__ __forceinline__ float value32(const float* a, const float* b) {
+  const float dx = a[0] - b[0], dy = a[1] - b[1];
+  if (METRIC == VCP_L1_2D) {
+    return fabsf(dx) + fabsf(dy);
+  } else if (METRIC == VCP_L2_2D) {
+    return dx * dx + dy * dy;
+  } else {
+    const float dz = a[2] - b[2];
+    return dx * dx + dy * dy + dz * dz;
+  }
+}
+
+// the predicate through the screen: binary32 where it is provably the binary64 answer, else the exact expression on
+// the binary64 coordinates of the two cell-ordered positions
+template <int GD, int METRIC>
+__device__ __forceinline__ bool within_scr(const float* qf, const float* cf, Screen sc, const double* q,
+                                           const double* __restrict__ sorted, uint32_t j, double thr) {
+  const float v = value32<METRIC>(qf, cf);
+  if (v <= sc.lo) return true;
+  if (v > sc.hi) return false;
+  double r[3];
+  load_pt<GD>(sorted, j, r);
+  return within<METRIC>(q, r, thr);
+}
+
 // ---- bounds ---------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_min(double v) {
 #pragma unroll
@@ -290,7 +317,7 @@ __global__ __launch_bounds__(TPB) void k_gather(const double* __restrict__ c, in
                                                const int32_t* __restrict__ group, const uint32_t* __restrict__ ord,
                                                uint32_t* __restrict__ pos, double* __restrict__ sorted,
                                                uint32_t* __restrict__ sord, int32_t* __restrict__ sgroup,
-                                               uint8_t* __restrict__ flags) {
+                                               uint8_t* __restrict__ flags, float* __restrict__ sorted32, GridP g) {
   const uint32_t nin = cellstart[ncells];
   int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
   if (p >= nin) return;
@@ -305,6 +332,7 @@ __global__ __launch_bounds__(TPB) void k_gather(const double* __restrict__ c, in
     sorted[3 * p + 1] = q[1];
     sorted[3 * p + 2] = q[2];
   }
+  store_pt32<GD>(sorted32, p, q, g);
   if (ord) sord[p] = ord[i];  // otherwise sidx IS sord (the sort wrote it there)
   if (GROUPED) sgroup[p] = group[i];
   if (in_classed) flags[p] = in_classed[i] ? F_CLASSED : 0;  // otherwise flags were zero-filled
@@ -493,7 +521,8 @@ __global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted,
                                              const uint32_t* __restrict__ cellstart,
                                              const int32_t* __restrict__ sgroup, uint8_t* __restrict__ flags,
                                              uint32_t* __restrict__ parent, uint32_t* __restrict__ minord,
-                                             uint32_t* __restrict__ blkE, uint32_t* __restrict__ blkB, NbrOut no) {
+                                             uint32_t* __restrict__ blkE, uint32_t* __restrict__ blkB, NbrOut no,
+                                             const float* __restrict__ sorted32, Screen sc) {
   extern __shared__ uint32_t lnb[];  // [NB * TPB] staged lists, then [NB * TPB] for their compaction
   const uint32_t nin = cellstart[g.ncells];
   const int64_t blk = xcd_block(gridDim.x);
@@ -505,25 +534,27 @@ __global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted,
     load_pt<GD>(sorted, p, q);
     cell_of<GD>(q, g, cc);
   }
-  constexpr int UNR = GD == 3 ? VCP_UNR3 : VCP_UNR2;
+  constexpr int UNR = GD == 3 ? 4 : VCP_UNR2;  // binary32 candidates: half the registers per candidate in flight
   const int32_t myg = (GROUPED && live) ? sgroup[p] : 0;
   int cnt = 0, nrec = 0;
   const int NB = no.NB;
+  float qf[3] = {0.f, 0.f, 0.f};
+  if (live) load_pt32<GD>(sorted32, p, qf);
   if (live) for_rows<GD>(cc, g, cellstart, [&](uint32_t s, uint32_t e) {
     // batches of UNR candidates: UNR independent loads in flight per lane (the loop is latency bound), the
-    // early exit is checked once per batch
+    // early exit is checked once per batch.  Candidates are screened on their binary32 copies (within_scr).
     for (uint32_t j = s; j < e; j += UNR) {
-      double r[UNR][3];
+      float r[UNR][3];
       int32_t gj[UNR];
 #pragma unroll
       for (int u = 0; u < UNR; u++) {
         const uint32_t jj = min(j + u, e - 1);
-        load_pt<GD>(sorted, jj, r[u]);
+        load_pt32<GD>(sorted32, jj, r[u]);
         if (GROUPED) gj[u] = sgroup[jj];
       }
 #pragma unroll
       for (int u = 0; u < UNR; u++) {
-        bool ok = (j + u < e) && within<METRIC>(q, r[u], thr);
+        bool ok = (j + u < e) && within_scr<GD, METRIC>(qf, r[u], sc, q, sorted, j + u, thr);
         if (GROUPED) ok = ok && gj[u] == myg;
         cnt += ok ? 1 : 0;
         if (ok && nrec < NB && j + u != (uint32_t)p) lnb[(nrec++) * TPB + threadIdx.x] = j + u;
@@ -564,10 +595,13 @@ __global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted,
 // (coalesced 16-B loads) and every lane scans its own sub-range from LDS instead of re-fetching the same lines
 // through L1 per lane.  If a staged range would exceed the tile (dense cells, a block spanning grid rows far
 // apart) the workgroup uses the global-memory loop.
-constexpr int TILE_CAP = 512;  // staged points per row: 3 x 512 x 16 B = 24 KB of LDS per workgroup
+constexpr int TILE_CAP = 512;  // staged points per row: 3 x 512 x 8 B = 12 KB of LDS per workgroup (binary32 copies)
 
 struct RowTile {
-  double2 pt[3][TILE_CAP];
+  union {
+    float2 pt[3][TILE_CAP];
+    uint32_t lout[15 * TPB];  // the neighbour lists are compacted here once the rows have been scanned
+  };
   uint32_t lo[3], hi[3];
 };
 
@@ -610,8 +644,8 @@ __device__ __forceinline__ bool tile_bounds(Tile& t, bool live, const int* cc, c
   return fits;
 }
 
-__device__ __forceinline__ void tile_load(RowTile& t, const double* __restrict__ sorted) {
-  const double2* __restrict__ src = reinterpret_cast<const double2*>(sorted);
+__device__ __forceinline__ void tile_load(RowTile& t, const float* __restrict__ sorted32) {
+  const float2* __restrict__ src = reinterpret_cast<const float2*>(sorted32);
 #pragma unroll
   for (int r = 0; r < 3; r++) {
     const uint32_t lo = t.lo[r], hi = t.hi[r];
@@ -674,7 +708,8 @@ template <int METRIC>
 __global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sorted, GridP g, double thr, int min_pts,
                                                  const uint32_t* __restrict__ cellstart, uint8_t* __restrict__ flags,
                                                  uint32_t* __restrict__ parent, uint32_t* __restrict__ minord,
-                                                 uint32_t* __restrict__ blkE, uint32_t* __restrict__ blkB, NbrOut no) {
+                                                 uint32_t* __restrict__ blkE, uint32_t* __restrict__ blkB, NbrOut no,
+                                                 const float* __restrict__ sorted32, Screen sc) {
   __shared__ RowTile t;
   const uint32_t nin = cellstart[g.ncells];
   const int64_t blk = xcd_block(gridDim.x);
@@ -682,8 +717,10 @@ __global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sor
   const bool live = p < nin;
   double q[3] = {0, 0, 0};
   int cc[3] = {0, 0, 0};
+  float qf[3] = {0.f, 0.f, 0.f};
   if (live) {
     load_pt<2>(sorted, p, q);
+    load_pt32<2>(sorted32, p, qf);
     cell_of<2>(q, g, cc);
   }
   uint32_t rs[3], re[3];
@@ -696,7 +733,7 @@ __global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sor
   // kernel); ovf = hits beyond the masks
   uint32_t hm[3] = {0u, 0u, 0u}, ovf = 0u;
   if (fits) {
-    tile_load(t, sorted);
+    tile_load(t, sorted32);
     if (live) {
 #pragma unroll
       for (int r = 0; r < 3; r++) {
@@ -704,14 +741,14 @@ __global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sor
         const uint32_t lo = t.lo[r];
         const uint32_t e = re[r] - lo, a = rs[r] - lo;
         for (uint32_t j = a; j < e; j += UNR) {
-          double2 c[UNR];
+          float2 c[UNR];
 #pragma unroll
           for (int u = 0; u < UNR; u++) c[u] = t.pt[r][min(j + u, e - 1)];
           uint32_t nib = 0;
 #pragma unroll
           for (int u = 0; u < UNR; u++) {
-            const double rr[3] = {c[u].x, c[u].y, 0.0};
-            nib |= ((j + u < e) && within<METRIC>(q, rr, thr)) ? (1u << u) : 0u;
+            const float rr[3] = {c[u].x, c[u].y, 0.0f};
+            nib |= ((j + u < e) && within_scr<2, METRIC>(qf, rr, sc, q, sorted, lo + j + u, thr)) ? (1u << u) : 0u;
           }
           cnt += __popc(nib);
           const uint32_t sh = j - a;
@@ -724,12 +761,13 @@ __global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sor
   } else if (live) {
     for (int r = 0; r < 3 && cnt < min_pts; r++) {
       for (uint32_t j = rs[r]; j < re[r]; j += UNR) {
-        double rr[UNR][3];
+        float rr[UNR][3];
 #pragma unroll
-        for (int u = 0; u < UNR; u++) load_pt<2>(sorted, min(j + u, re[r] - 1), rr[u]);
+        for (int u = 0; u < UNR; u++) load_pt32<2>(sorted32, min(j + u, re[r] - 1), rr[u]);
         uint32_t nib = 0;
 #pragma unroll
-        for (int u = 0; u < UNR; u++) nib |= ((j + u < re[r]) && within<METRIC>(q, rr[u], thr)) ? (1u << u) : 0u;
+        for (int u = 0; u < UNR; u++)
+          nib |= ((j + u < re[r]) && within_scr<2, METRIC>(qf, rr[u], sc, q, sorted, j + u, thr)) ? (1u << u) : 0u;
         cnt += __popc(nib);
         const uint32_t sh = j - rs[r];
         hm[r] |= sh < 32u ? nib << sh : 0u;
@@ -774,8 +812,7 @@ __global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sor
     parent[p] = isE ? (uint32_t)p : NONE;
     minord[p] = NONE;
   }
-  nbr_flush_masks<METRIC>(no, reinterpret_cast<uint32_t*>(&t.pt[0][0]), hm, rs, re, rescan, nrec, q, thr, sorted, blk, p,
-                          live);
+  nbr_flush_masks<METRIC>(no, t.lout, hm, rs, re, rescan, nrec, q, thr, sorted, blk, p, live);
   wl_count(isE, isB, (uint32_t)blk, blkE, blkB);
 }
 
@@ -931,14 +968,16 @@ template <int GD, int METRIC, bool GROUPED, bool PRE>
 __global__ __launch_bounds__(TPB) void k_union(const double* __restrict__ sorted, GridP g, double thr,
                                               const uint32_t* __restrict__ cellstart,
                                               const int32_t* __restrict__ sgroup, uint32_t* __restrict__ parent,
-                                              WorkList wlE) {
+                                              WorkList wlE, const float* __restrict__ sorted32, Screen sc) {
   const uint32_t p = wl_fetch(wlE);
   if (p == NONE) return;
   constexpr int NR = GD == 3 ? 9 : 3;
   uint32_t rs[NR], re[NR];
   double q[3];
+  float qf[3];
   int cc[3];
   load_pt<GD>(sorted, p, q);
+  load_pt32<GD>(sorted32, p, qf);
   cell_of<GD>(q, g, cc);
   row_bounds<GD>(cc, g, cellstart, rs, re);
   constexpr int UNR = PRE ? VCP_UNRW : (GD == 3 ? VCP_UNR3 : VCP_UNR2);
@@ -953,20 +992,12 @@ __global__ __launch_bounds__(TPB) void k_union(const double* __restrict__ sorted
     const uint32_t e = min(re[r], me);  // every undirected edge is handled by its larger endpoint
     for (uint32_t j0 = s; j0 < e; j0 += UNR) {
       uint32_t pj[UNR];
-      double2 xy[UNR];
-      double zz[UNR];
+      float cf[UNR][3];
 #pragma unroll
       for (int u = 0; u < UNR; u++) {
         const uint32_t jj = min(j0 + u, e - 1);
         pj[u] = ld_parent_cached(parent, jj);
-        if (!PRE) {
-          if (GD == 2) {
-            xy[u] = *reinterpret_cast<const double2*>(sorted + 2 * (int64_t)jj);
-          } else {
-            xy[u] = make_double2(sorted[3 * (int64_t)jj], sorted[3 * (int64_t)jj + 1]);
-            zz[u] = sorted[3 * (int64_t)jj + 2];
-          }
-        }
+        if (!PRE) load_pt32<GD>(sorted32, jj, cf[u]);
       }
 #pragma unroll
       for (int u = 0; u < UNR; u++) {
@@ -976,25 +1007,8 @@ __global__ __launch_bounds__(TPB) void k_union(const double* __restrict__ sorted
         if (j >= e || x == NONE || x == rp) continue;
         if (PRE && (x == a0 || x == a1 || x == a2 || x == q0 || x == q1)) continue;
         if (GROUPED && sgroup[j] != myg) continue;
-        if (PRE) {
-          if (GD == 2) {
-            xy[u] = *reinterpret_cast<const double2*>(sorted + 2 * (int64_t)j);
-          } else {
-            xy[u] = make_double2(sorted[3 * (int64_t)j], sorted[3 * (int64_t)j + 1]);
-            zz[u] = sorted[3 * (int64_t)j + 2];
-          }
-        }
-        const double dx = q[0] - xy[u].x, dy = q[1] - xy[u].y;
-        bool hit;
-        if (METRIC == VCP_L1_2D) {
-          hit = fabs(dx) + fabs(dy) <= thr;
-        } else if (METRIC == VCP_L2_2D) {
-          hit = dx * dx + dy * dy <= thr;
-        } else {
-          const double dz = q[2] - zz[u];
-          hit = dx * dx + dy * dy + dz * dz <= thr;
-        }
-        if (!hit) continue;
+        if (PRE) load_pt32<GD>(sorted32, j, cf[u]);
+        if (!within_scr<GD, METRIC>(qf, cf[u], sc, q, sorted, j, thr)) continue;
         if (!PRE) {
           // second hop: j's tree was hooked under my root by an earlier edge (one L2 load instead of two chases)
           const uint32_t x2 = ld_parent_cached(parent, x);
@@ -1453,6 +1467,46 @@ double l2_threshold(double eps) {
   return t;
 }
 
+// Screen bounds (see grid_common.hpp).  E = largest |coordinate - grid origin| over the finite input (from the TRUE
+// bounding box: the grid range may have been trimmed), u = 2^-24.  A screening copy is off by at most u E (1 + u); a
+// coordinate difference a of two copies satisfies |a - d| <= alpha + u |d| with alpha = 2 u E (1 + 2u).
+//   L1:  |s - m| <= A + B m,  A = 2 alpha (1 + u),  B = 2 u (1 + u)        (m = exact |dx| + |dy|, s = binary32 value)
+//   L2:  |s - m| <= 2 alpha sqrt(GD m)(1 + u) + GD alpha^2 + 6 u m (1 + u) (m = exact sum of squares)
+// plus 1e-14 m for the roundings of the binary64 reference expression itself.  err() grows with m, so s > thr + err(thr)
+// proves m > thr; m - err(m) grows with m as long as sqrt(m) dominates alpha, so s <= thr - err(thr) proves m <= thr (when
+// it does not, lo = -1: nothing is accepted on binary32 evidence).  lo is rounded down, hi up.
+Screen screen_bounds(int metric, int gd, double thr, double E) {
+  Screen sc;
+  sc.lo = -1.0f;
+  sc.hi = INFINITY;
+  if (!(thr >= 0.0) || !std::isfinite(E)) return sc;  // NaN / negative thresholds and unbounded clouds: all exact
+  const double u = 5.9604644775390625e-08;
+  const double alpha = 2.0 * u * E * (1.0 + 2.0 * u);
+  double err;
+  bool lo_ok = true;
+  if (metric == VCP_L1_2D) {
+    err = 2.0 * alpha * (1.0 + u) + 2.0 * u * (1.0 + u) * thr;
+  } else {
+    err = 2.0 * alpha * std::sqrt((double)gd * thr) * (1.0 + u) + (double)gd * alpha * alpha + 6.0 * u * (1.0 + u) * thr;
+    lo_ok = std::sqrt(thr) > 4.0 * alpha * std::sqrt((double)gd);
+  }
+  err = err * 1.0625 + 1e-14 * thr + 1e-300;
+  const double lo = thr - err, hi = thr + err;
+  if (std::isfinite(hi)) {
+    float h = (float)hi;
+    if ((double)h < hi) h = std::nextafterf(h, INFINITY);
+    sc.hi = h;
+  }
+  if (lo_ok && lo >= 0.0 && std::isfinite(lo)) {
+    float l = (float)lo;
+    if ((double)l > lo) l = std::nextafterf(l, -INFINITY);
+    sc.lo = l;
+  } else if (lo_ok && std::isinf(thr) && thr > 0) {
+    sc.lo = 3.4028234663852886e38f;  // eps = +inf: every finite value is inside
+  }
+  return sc;
+}
+
 // workgroups per band of a work list: a band holds at most ceil(n / (8*LCHUNK)) entries
 unsigned list_perblk(int64_t n) {
   const int64_t band = (n + 8 * LCHUNK - 1) / (8 * LCHUNK) + 1;
@@ -1520,6 +1574,12 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   }
 
   // 2. grid geometry (host): cell edge a hair above eps; coarsen until the cell count fits
+  double bbox[6];  // the true bounding box of the finite coordinates (the grid range below may get trimmed)
+  for (int a = 0; a < 3; a++) {
+    const bool have = a < GD && h[3 + a] >= h[a];
+    bbox[a] = have ? h[a] : 0.0;
+    bbox[3 + a] = have ? h[3 + a] : 0.0;
+  }
   GridP g;
   double range = 0.0;
   for (int a = 0; a < 3; a++) {
@@ -1614,6 +1674,7 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   VCP_TRY(vcp_ensure(ctx, ctx->b_rank, (size_t)n * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_pos, (size_t)n * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_sorted, (size_t)n * GD * 8));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_sorted32, (size_t)n * (GD == 2 ? 2 : 4) * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_sidx, (size_t)n * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_flags, (size_t)n));
   VCP_TRY(vcp_ensure(ctx, ctx->b_parent, (size_t)n * 4));
@@ -1629,6 +1690,13 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   uint32_t* rank = ctx->b_rank.as<uint32_t>();
   uint32_t* pos = ctx->b_pos.as<uint32_t>();
   double* sorted = ctx->b_sorted.as<double>();
+  float* sorted32 = ctx->b_sorted32.as<float>();
+  // largest |coordinate - grid origin| over the finite input: the true bounding box, not the (possibly trimmed) grid
+  double Emax = 0.0;
+  for (int a = 0; a < GD; a++) Emax = std::fmax(Emax, std::fmax(std::fabs(bbox[a] - g.mn[a]), std::fabs(bbox[3 + a] - g.mn[a])));
+  static const bool screen_off = getenv("VCP_NO_SCREEN") != nullptr;
+  Screen sc = screen_bounds(METRIC, GD, thr, Emax);
+  if (screen_off) sc = Screen{-1.0f, INFINITY};
   uint32_t* sord = ctx->b_sidx.as<uint32_t>();
   uint8_t* flags = ctx->b_flags.as<uint8_t>();
   uint32_t* parent = ctx->b_parent.as<uint32_t>();
@@ -1663,6 +1731,7 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
     ga.d_in_classed = d_in_classed;
     ga.cellstart = cellcnt;
     ga.sorted = sorted;
+    ga.sorted32 = sorted32;
     ga.sord = sord;
     ga.sgroup = sgroup;
     ga.flags = flags;
@@ -1694,7 +1763,7 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
     vcp_phase(ctx, "scatter");
     if (!d_in_classed) VCP_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)n, st));
     hipLaunchKernelGGL((k_gather<GD, GROUPED>), dim3(nb), dim3(TPB), 0, st, d_coords, stride, cellcnt, g.ncells, sidx,
-                       d_in_classed, d_group, d_ord, pos, sorted, sord, sgroup, flags);
+                       d_in_classed, d_group, d_ord, pos, sorted, sord, sgroup, flags, sorted32, g);
   }
 
   // 5. core flags + work lists (expanding points; non-core points that have a neighbour)
@@ -1725,10 +1794,10 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   const size_t lds_nb = (size_t)no.NB * TPB * 4;
   if constexpr (GD == 2 && !GROUPED)
     hipLaunchKernelGGL((k_core_lds<METRIC>), dim3(nb), dim3(TPB), 0, st, sorted, g, thr, min_pts, cellcnt, flags, parent,
-                       minord, blkE, blkB, no);
+                       minord, blkE, blkB, no, sorted32, sc);
   else
     hipLaunchKernelGGL((k_core<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 2 * lds_nb, st, sorted, g, thr, min_pts, cellcnt,
-                       sgroup, flags, parent, minord, blkE, blkB, no);
+                       sgroup, flags, parent, minord, blkE, blkB, no, sorted32, sc);
   VCP_TRY(vcp_exclusive_scan_u32(ctx, blkE, blkE, (int64_t)nb + 1, nullptr));
   VCP_TRY(vcp_exclusive_scan_u32(ctx, blkB, blkB, (int64_t)nb + 1, nullptr));
   hipLaunchKernelGGL(k_wl_fill, dim3(nb), dim3(TPB), 0, st, flags, cellcnt, g.ncells, blkE, blkB, wlE.list, wlB.list);
@@ -1749,10 +1818,10 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   }
   if (pre)
     hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED, true>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup,
-                       parent, wlE);
+                       parent, wlE, sorted32, sc);
   else
     hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED, false>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup,
-                       parent, wlE);
+                       parent, wlE, sorted32, sc);
   vcp_phase(ctx, "flatten_number");
   hipLaunchKernelGGL(k_flatten, dim3(nbl), dim3(TPB), 0, st, parent, sord, minord, wlE);
   if (!GROUPED && ext && ext->slab) {

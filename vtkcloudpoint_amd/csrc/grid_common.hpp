@@ -79,6 +79,39 @@ __device__ __forceinline__ uint32_t cell_of(const double* q, const GridP& g, int
   return cell_id<GD>(g, cc[0], cc[1], cc[2]);
 }
 
+// ---- binary32 screening of the distance predicate ----------------------------------------------------------
+// The search kernels decide `d(p, j) <= eps` on binary32 copies of the coordinates, taken relative to the grid origin,
+// wherever that decision is provably the binary64 one: value <= lo -> inside, value > hi -> outside, anything else
+// (also NaN) is re-tested with the reference's exact binary64 expression.  lo / hi come from a rounding analysis on
+// the host (screen_bounds in dbscan.hip); half the bytes per candidate and a quarter of the FP64 work in 3-D.
+struct Screen {
+  float lo, hi;
+};
+
+// coordinates of cell-ordered point p relative to the grid origin, in binary32 (2-D: float2, 3-D: float4 with w unused)
+template <int GD>
+__device__ __forceinline__ void load_pt32(const float* __restrict__ c, int64_t i, float* q) {
+  if (GD == 2) {
+    const float2 v = *reinterpret_cast<const float2*>(c + 2 * i);
+    q[0] = v.x;
+    q[1] = v.y;
+  } else {
+    const float4 v = *reinterpret_cast<const float4*>(c + 4 * i);
+    q[0] = v.x;
+    q[1] = v.y;
+    q[2] = v.z;
+  }
+}
+template <int GD>
+__device__ __forceinline__ void store_pt32(float* __restrict__ c, int64_t i, const double* q, const GridP& g) {
+  if (GD == 2) {
+    *reinterpret_cast<float2*>(c + 2 * i) = make_float2((float)(q[0] - g.mn[0]), (float)(q[1] - g.mn[1]));
+  } else {
+    *reinterpret_cast<float4*>(c + 4 * i) =
+        make_float4((float)(q[0] - g.mn[0]), (float)(q[1] - g.mn[1]), (float)(q[2] - g.mn[2]), 0.0f);
+  }
+}
+
 }  // namespace vcpg
 
 // ---- grid build by two-level partition (gridbuild.hip) ------------------------------------------------------
@@ -97,6 +130,7 @@ struct GridBuildArgs {
   // outputs (cell order unless noted)
   uint32_t* cellstart = nullptr;  // [ncells + 1]
   double* sorted = nullptr;       // [nin * gd]
+  float* sorted32 = nullptr;      // [nin * (gd == 2 ? 2 : 4)] binary32 copies relative to g.mn (screening)
   uint32_t* sord = nullptr;       // [nin]
   int32_t* sgroup = nullptr;      // [nin], grouped only
   uint8_t* flags = nullptr;       // [nin], written only with d_in_classed

@@ -153,9 +153,9 @@ __global__ __launch_bounds__(FT) void k_part_fine(const Rec* __restrict__ rec, c
                                                  uint32_t csh, GridP g, const uint32_t* __restrict__ ord,
                                                  const uint8_t* __restrict__ in_classed,
                                                  const int32_t* __restrict__ group, uint32_t* __restrict__ cellstart,
-                                                 double* __restrict__ sorted, uint32_t* __restrict__ sord,
-                                                 int32_t* __restrict__ sgroup, uint8_t* __restrict__ flags,
-                                                 uint32_t* __restrict__ pos) {
+                                                 double* __restrict__ sorted, float* __restrict__ sorted32,
+                                                 uint32_t* __restrict__ sord, int32_t* __restrict__ sgroup,
+                                                 uint8_t* __restrict__ flags, uint32_t* __restrict__ pos) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   __shared__ uint32_t wsum[FT / 64];
   const uint32_t b = blockIdx.x;
@@ -214,6 +214,7 @@ __global__ __launch_bounds__(FT) void k_part_fine(const Rec* __restrict__ rec, c
       sidx[p - s] = i;
     } else {
       store_pt<GD>(sorted, p, q);
+      store_pt32<GD>(sorted32, p, q, g);
       sord[p] = ord ? ord[i] : i;
       if (GROUPED) sgroup[p] = group[i];
       if (in_classed) flags[p] = in_classed[i] ? F_CLASSED : 0;
@@ -226,9 +227,15 @@ __global__ __launch_bounds__(FT) void k_part_fine(const Rec* __restrict__ rec, c
   if (GD == 2) {
     const double2* src = reinterpret_cast<const double2*>(sxy);
     double2* dst = reinterpret_cast<double2*>(sorted) + s;
-    for (uint32_t k = threadIdx.x; k < m; k += FT) dst[k] = src[k];
+    float2* dst32 = reinterpret_cast<float2*>(sorted32) + s;
+    for (uint32_t k = threadIdx.x; k < m; k += FT) {
+      const double2 v = src[k];
+      dst[k] = v;
+      dst32[k] = make_float2((float)(v.x - g.mn[0]), (float)(v.y - g.mn[1]));
+    }
   } else {
     for (uint32_t k = threadIdx.x; k < 3 * m; k += FT) sorted[(size_t)3 * s + k] = sxy[k];
+    for (uint32_t k = threadIdx.x; k < m; k += FT) store_pt32<GD>(sorted32, (int64_t)s + k, sxy + (size_t)3 * k, g);
   }
   for (uint32_t k = threadIdx.x; k < m; k += FT) {
     const uint32_t i = sidx[k], p = s + k;
@@ -366,8 +373,8 @@ int build(vcp_ctx* ctx, const GridBuildArgs& a) {
                      a.d_group, a.glo, a.ghi, pg.csh, pg.B, pg.chunk, pg.nchunk, counts, rec, a.pos);
   vcp_phase(ctx, "part_fine");
   hipLaunchKernelGGL((k_part_fine<GD, GROUPED>), dim3(pg.B), dim3(FT), lds_f, st, rec, counts, total, pg.nchunk, pg.B,
-                     pg.csh, a.g, a.d_ord, a.d_in_classed, a.d_group, a.cellstart, a.sorted, a.sord, a.sgroup, a.flags,
-                     a.pos);
+                     pg.csh, a.g, a.d_ord, a.d_in_classed, a.d_group, a.cellstart, a.sorted, a.sorted32, a.sord, a.sgroup,
+                     a.flags, a.pos);
   VCP_HIP(ctx, hipGetLastError());
   return VCP_OK;
 }

@@ -589,43 +589,53 @@ __global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted,
   wl_count(isE, isB, (uint32_t)blk, blkE, blkB);
 }
 
-// ---- LDS-staged candidate rows (2-D, ungrouped) -----------------------------------------------------
-// A workgroup covers 256 consecutive positions = a run of cells along x, so the three candidate rows of all
-// its lanes are (almost always) three short contiguous position ranges.  They are staged once per workgroup
-// (coalesced 16-B loads) and every lane scans its own sub-range from LDS instead of re-fetching the same lines
-// through L1 per lane.  If a staged range would exceed the tile (dense cells, a block spanning grid rows far
-// apart) the workgroup uses the global-memory loop.
-constexpr int TILE_CAP = 512;  // staged points per row: 3 x 512 x 8 B = 12 KB of LDS per workgroup (binary32 copies)
-
-struct RowTile {
+// ---- LDS-staged candidate rows (ungrouped) -----------------------------------------------------------
+// A workgroup covers 256 consecutive positions = a run of cells along x, so the three candidate rows of all its lanes
+// are (almost always) three short contiguous position ranges.  Their binary32 screening copies are
+// staged once per workgroup (coalesced loads) and every lane scans its own sub-range from LDS instead of re-fetching
+// the same lines through L1 per lane.  If a staged range would exceed the tile (dense cells, a block spanning grid rows
+// far apart) the workgroup uses the global-memory loop.
+template <int GD>
+struct CoreTile;
+template <>
+struct CoreTile<2> {  // 3 rows x 512 x 8 B = 12 KB
+  static constexpr int NR = 3, CAP = 512;
   union {
-    float2 pt[3][TILE_CAP];
+    float2 pt[3][512];
     uint32_t lout[15 * TPB];  // the neighbour lists are compacted here once the rows have been scanned
   };
   uint32_t lo[3], hi[3];
+  __device__ __forceinline__ void put(int r, uint32_t k, const float* __restrict__ s32, uint32_t pos) {
+    pt[r][k] = reinterpret_cast<const float2*>(s32)[pos];
+  }
+  __device__ __forceinline__ void get(int r, uint32_t k, float* c) const {
+    const float2 v = pt[r][k];
+    c[0] = v.x;
+    c[1] = v.y;
+  }
 };
+// (A 3-D tile -- 9 rows x 384 x 12 B -- was built and measured: 1.79 ms against 1.20 ms for the global-memory loop on the
+// 10 M-point L2_3D cloud.  41 KB of LDS leave three workgroups per CU and dense cells overflow the tile; 3-D keeps k_core.)
 
 // row bounds of this lane (rs >= re for a missing row) and the workgroup's union per row in t.lo / t.hi;
-// returns true when all three ranges fit the tile (uniform over the workgroup)
-template <class Tile, int CAP>
-__device__ __forceinline__ bool tile_bounds(Tile& t, bool live, const int* cc, const GridP& g,
+// returns true when every range fits the tile (uniform over the workgroup)
+template <int GD>
+__device__ __forceinline__ bool tile_bounds(CoreTile<GD>& t, bool live, const int* cc, const GridP& g,
                                             const uint32_t* __restrict__ cellstart, uint32_t* rs, uint32_t* re) {
-  if (threadIdx.x < 3) {
+  constexpr int NR = CoreTile<GD>::NR;
+  if (threadIdx.x < NR) {
     t.lo[threadIdx.x] = NONE;
     t.hi[threadIdx.x] = 0u;
   }
-  const int x0 = max(cc[0] - 1, 0), x1 = min(cc[0] + 1, g.D[0] - 1);
+  if (live) {
+    row_bounds<GD>(cc, g, cellstart, rs, re);
+  } else {
 #pragma unroll
-  for (int r = 0; r < 3; r++) {
-    const int y = cc[1] + r - 1;
-    const bool ok = live && y >= 0 && y < g.D[1];
-    const uint32_t base = ok ? cell_id<2>(g, 0, y, 0) : 0u;
-    rs[r] = ok ? cellstart[base + x0] : 0u;
-    re[r] = ok ? cellstart[base + x1 + 1] : 0u;
+    for (int r = 0; r < NR; r++) rs[r] = re[r] = 0u;
   }
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < 3; r++) {
+  for (int r = 0; r < NR; r++) {
     uint32_t a = rs[r] < re[r] ? rs[r] : NONE, b = rs[r] < re[r] ? re[r] : 0u;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
@@ -640,17 +650,17 @@ __device__ __forceinline__ bool tile_bounds(Tile& t, bool live, const int* cc, c
   __syncthreads();
   bool fits = true;
 #pragma unroll
-  for (int r = 0; r < 3; r++) fits = fits && (t.hi[r] <= t.lo[r] || t.hi[r] - t.lo[r] <= (uint32_t)CAP);
+  for (int r = 0; r < NR; r++) fits = fits && (t.hi[r] <= t.lo[r] || t.hi[r] - t.lo[r] <= (uint32_t)CoreTile<GD>::CAP);
   return fits;
 }
 
-__device__ __forceinline__ void tile_load(RowTile& t, const float* __restrict__ sorted32) {
-  const float2* __restrict__ src = reinterpret_cast<const float2*>(sorted32);
+template <int GD>
+__device__ __forceinline__ void tile_load(CoreTile<GD>& t, const float* __restrict__ sorted32) {
 #pragma unroll
-  for (int r = 0; r < 3; r++) {
+  for (int r = 0; r < CoreTile<GD>::NR; r++) {
     const uint32_t lo = t.lo[r], hi = t.hi[r];
     if (hi > lo)
-      for (uint32_t k = threadIdx.x; k < hi - lo; k += TPB) t.pt[r][k] = src[lo + k];
+      for (uint32_t k = threadIdx.x; k < hi - lo; k += TPB) t.put(r, k, sorted32, lo + k);
   }
   __syncthreads();
 }
@@ -659,11 +669,12 @@ __device__ __forceinline__ void tile_load(RowTile& t, const float* __restrict__ 
 // the count is a popcount, the block-wide compaction offset a scan of the counts, and the positions are read off the
 // masks straight into the compacted image -- which reuses the row tile once every lane is done with it.  A lane with a
 // hit beyond the masks that stays below min_pts (`rescan`) walks its rows again in global memory: rare.
-template <int METRIC>
+template <int GD, int METRIC>
 __device__ __forceinline__ void nbr_flush_masks(const NbrOut& no, uint32_t* lout, const uint32_t* hm, const uint32_t* rs,
                                                 const uint32_t* re, bool rescan, int nrec, const double* q, double thr,
                                                 const double* __restrict__ sorted, int64_t blk, int64_t p, bool live) {
   if (no.NB == 0) return;
+  constexpr int NR = CoreTile<GD>::NR;
   __shared__ uint32_t wtot[TPB / 64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   uint32_t inc = (uint32_t)nrec;
@@ -682,15 +693,15 @@ __device__ __forceinline__ void nbr_flush_masks(const NbrOut& no, uint32_t* lout
   if (live) no.off[p] = (uint16_t)pre;
   int k = 0;
   if (rescan) {
-    for (int r = 0; r < 3; r++)
+    for (int r = 0; r < NR; r++)
       for (uint32_t j = rs[r]; j < re[r] && k < nrec; j++) {
         double rr[3];
-        load_pt<2>(sorted, j, rr);
+        load_pt<GD>(sorted, j, rr);
         if (j != (uint32_t)p && within<METRIC>(q, rr, thr)) lout[pre + (k++)] = j;
       }
   } else {
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
+    for (int r = 0; r < NR; r++) {
       uint32_t m = hm[r];
       while (m != 0u && k < nrec) {
         const uint32_t pos = rs[r] + (uint32_t)(__ffs((int)m) - 1);
@@ -704,13 +715,15 @@ __device__ __forceinline__ void nbr_flush_masks(const NbrOut& no, uint32_t* lout
   for (uint32_t i = threadIdx.x; i < total; i += TPB) dst[i] = lout[i];
 }
 
-template <int METRIC>
+template <int GD, int METRIC>
 __global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sorted, GridP g, double thr, int min_pts,
                                                  const uint32_t* __restrict__ cellstart, uint8_t* __restrict__ flags,
                                                  uint32_t* __restrict__ parent, uint32_t* __restrict__ minord,
                                                  uint32_t* __restrict__ blkE, uint32_t* __restrict__ blkB, NbrOut no,
                                                  const float* __restrict__ sorted32, Screen sc) {
-  __shared__ RowTile t;
+  constexpr int NR = CoreTile<GD>::NR;
+  constexpr int OWN = NR / 2;  // the row of the point's own cell (dy = dz = 0)
+  __shared__ CoreTile<GD> t;
   const uint32_t nin = cellstart[g.ncells];
   const int64_t blk = xcd_block(gridDim.x);
   int64_t p = blk * TPB + threadIdx.x;
@@ -719,37 +732,36 @@ __global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sor
   int cc[3] = {0, 0, 0};
   float qf[3] = {0.f, 0.f, 0.f};
   if (live) {
-    load_pt<2>(sorted, p, q);
-    load_pt32<2>(sorted32, p, qf);
-    cell_of<2>(q, g, cc);
+    load_pt<GD>(sorted, p, q);
+    load_pt32<GD>(sorted32, p, qf);
+    cell_of<GD>(q, g, cc);
   }
-  uint32_t rs[3], re[3];
-  const bool fits = tile_bounds<RowTile, TILE_CAP>(t, live, cc, g, cellstart, rs, re);
-  constexpr int UNR = VCP_UNR2;
-  static_assert(UNR == 4, "hit nibbles");
+  uint32_t rs[NR], re[NR];
+  const bool fits = tile_bounds<GD>(t, live, cc, g, cellstart, rs, re);
+  constexpr int UNR = 4;  // hit nibbles
   int cnt = 0;
   // per row a bit mask of which of the lane's first 32 candidates were hits (two extra VALU operations per candidate;
   // writing positions to LDS as they were found cost seven, plus the LDS that held them: 0.2 ms on this VALU-bound
   // kernel); ovf = hits beyond the masks
-  uint32_t hm[3] = {0u, 0u, 0u}, ovf = 0u;
+  uint32_t hm[NR], ovf = 0u;
+#pragma unroll
+  for (int r = 0; r < NR; r++) hm[r] = 0u;
   if (fits) {
-    tile_load(t, sorted32);
+    tile_load<GD>(t, sorted32);
     if (live) {
 #pragma unroll
-      for (int r = 0; r < 3; r++) {
+      for (int r = 0; r < NR; r++) {
         if (cnt >= min_pts || rs[r] >= re[r]) continue;
         const uint32_t lo = t.lo[r];
         const uint32_t e = re[r] - lo, a = rs[r] - lo;
         for (uint32_t j = a; j < e; j += UNR) {
-          float2 c[UNR];
+          float c[UNR][3];
 #pragma unroll
-          for (int u = 0; u < UNR; u++) c[u] = t.pt[r][min(j + u, e - 1)];
+          for (int u = 0; u < UNR; u++) t.get(r, min(j + u, e - 1), c[u]);
           uint32_t nib = 0;
 #pragma unroll
-          for (int u = 0; u < UNR; u++) {
-            const float rr[3] = {c[u].x, c[u].y, 0.0f};
-            nib |= ((j + u < e) && within_scr<2, METRIC>(qf, rr, sc, q, sorted, lo + j + u, thr)) ? (1u << u) : 0u;
-          }
+          for (int u = 0; u < UNR; u++)
+            nib |= ((j + u < e) && within_scr<GD, METRIC>(qf, c[u], sc, q, sorted, lo + j + u, thr)) ? (1u << u) : 0u;
           cnt += __popc(nib);
           const uint32_t sh = j - a;
           hm[r] |= sh < 32u ? nib << sh : 0u;
@@ -759,15 +771,17 @@ __global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sor
       }
     }
   } else if (live) {
-    for (int r = 0; r < 3 && cnt < min_pts; r++) {
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+      if (cnt >= min_pts) continue;
       for (uint32_t j = rs[r]; j < re[r]; j += UNR) {
         float rr[UNR][3];
 #pragma unroll
-        for (int u = 0; u < UNR; u++) load_pt32<2>(sorted32, min(j + u, re[r] - 1), rr[u]);
+        for (int u = 0; u < UNR; u++) load_pt32<GD>(sorted32, min(j + u, re[r] - 1), rr[u]);
         uint32_t nib = 0;
 #pragma unroll
         for (int u = 0; u < UNR; u++)
-          nib |= ((j + u < re[r]) && within_scr<2, METRIC>(qf, rr[u], sc, q, sorted, j + u, thr)) ? (1u << u) : 0u;
+          nib |= ((j + u < re[r]) && within_scr<GD, METRIC>(qf, rr[u], sc, q, sorted, j + u, thr)) ? (1u << u) : 0u;
         cnt += __popc(nib);
         const uint32_t sh = j - rs[r];
         hm[r] |= sh < 32u ? nib << sh : 0u;
@@ -784,9 +798,10 @@ __global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sor
     if (rescan) {
       nrec = max(cnt - 1, 0);
     } else {
-      nrec = __popc(hm[0]) + __popc(hm[1]) + __popc(hm[2]);
-      const uint32_t sb = (uint32_t)p - rs[1];  // the point itself sits in its own row (a NaN point has no hit at all)
-      if (rs[1] < re[1] && sb < 32u && ((hm[1] >> sb) & 1u)) nrec--;
+#pragma unroll
+      for (int r = 0; r < NR; r++) nrec += __popc(hm[r]);
+      const uint32_t sb = (uint32_t)p - rs[OWN];  // the point itself sits in its own row (a NaN point has no hit at all)
+      if (rs[OWN] < re[OWN] && sb < 32u && ((hm[OWN] >> sb) & 1u)) nrec--;
     }
     nrec = min(nrec, no.NB);
   }
@@ -812,7 +827,7 @@ __global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sor
     parent[p] = isE ? (uint32_t)p : NONE;
     minord[p] = NONE;
   }
-  nbr_flush_masks<METRIC>(no, t.lout, hm, rs, re, rescan, nrec, q, thr, sorted, blk, p, live);
+  nbr_flush_masks<GD, METRIC>(no, t.lout, hm, rs, re, rescan, nrec, q, thr, sorted, blk, p, live);
   wl_count(isE, isB, (uint32_t)blk, blkE, blkB);
 }
 
@@ -1793,7 +1808,7 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   }
   const size_t lds_nb = (size_t)no.NB * TPB * 4;
   if constexpr (GD == 2 && !GROUPED)
-    hipLaunchKernelGGL((k_core_lds<METRIC>), dim3(nb), dim3(TPB), 0, st, sorted, g, thr, min_pts, cellcnt, flags, parent,
+    hipLaunchKernelGGL((k_core_lds<GD, METRIC>), dim3(nb), dim3(TPB), 0, st, sorted, g, thr, min_pts, cellcnt, flags, parent,
                        minord, blkE, blkB, no, sorted32, sc);
   else
     hipLaunchKernelGGL((k_core<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 2 * lds_nb, st, sorted, g, thr, min_pts, cellcnt,

@@ -40,13 +40,26 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 # Algorithmic bytes per point of each kernel phase for the 2-D binary64 path: what the
 # phase must read/write once if every neighbour access hits cache.
 ALGO_BYTES_PER_POINT = {
-    # grid build by two-level partition: histogram pass reads the coordinates; the scatter carries (x, y, index);
-    # the fine pass reads the records, writes cell order + 4 B per cell of the cell table (~5 cells per point here)
-    "bounds": 16, "part_hist": 16, "part_scatter": 16 + 20, "part_fine": 20 + 20 + 20,
-    # sort-based build (fallback path)
-    "cell_key": 24, "cell_sort": 48, "cell_scan": 24, "scatter": 48,
-    "core_count": 18, "union": 25, "flatten_number": 24, "border": 21,
-    "output": 14, "out_scatter": 16, "out_write": 14,
+    "bounds": 16,               # R coords
+    "part_hist": 16,            # R coords (the chunk x bucket counts are ~0.4 B per point)
+    "part_scatter": 16 + 32,    # R coords, W one 32-byte record (x, y, index)
+    # R records (the second read of a bucket is served by L2); W sorted 16 + binary32 copy 8 + list position 4 +
+    # 4 B per cell of the cell table (5 cells per point on this cloud)
+    "part_fine": 32 + 16 + 8 + 4 + 20,
+    # R own point 16 + 8, staged binary32 rows ~8, flags 1; W flags 1, parent 4, minord 4, neighbour lists (3.6 entries
+    # per point on this cloud) 14.5 + offset 2; work-list fill R 1 + W 2.4
+    "core_count": 54,
+    # list links R 1 + 9 per expanding point (a quarter of the points) ..., candidate parent words (cache-served, once
+    # per point), coordinates of the expanding points
+    "union": 25,
+    "flatten_number": 10,       # work-list kernels over the expanding points + seed bitmap
+    # rank extension R 5 + W 8 for every point; list walk (flags, ~3 list words, ~3 rank words, sord, labk) for the third
+    # of the points that are border candidates
+    "border": 24,
+    "out_scatter": 8 + 8,       # R (list position, label word), W the 8-byte record
+    "out_write": 8 + 6,         # R record, W label 4 + isKeyPoint 1 + isClassed 1
+    # sort-based build and gather output (fallback for grids beyond the one-level partition)
+    "cell_key": 24, "cell_sort": 48, "cell_scan": 24, "scatter": 48, "output": 14,
 }
 
 BLOCK_DEFAULTS = dict(eps=0.07, min_pts=7, pts_in_cell=200, small_max=3)  # Clustering.Designer.cs:86,96,158

@@ -18,14 +18,18 @@ import sys
 from collections import defaultdict
 
 PHASE_OF = {
-    "k_bounds": "bounds", "k_bounds_final": "bounds", "k_cell_key": "cell_key", "rocprim_radix_sort": "cell_sort",
-    "k_tile_marks": "cell_scan", "k_cellstart_tiles": "cell_scan", "k_gather": "scatter",
-    "k_scan_tile_sums": "cell_scan", "k_scan_offsets": "cell_scan", "k_scan_tiles": "cell_scan",
+    "k_bounds": "bounds", "k_bounds_final": "bounds",
+    # grid build by partition (round 2) / by sort (fallback for huge grids)
+    "k_part_hist": "part_hist", "k_part_scatter": "part_scatter", "k_part_fine": "part_fine",
+    "k_cell_key": "cell_key", "rocprim_radix_sort": "cell_sort", "k_tile_marks": "cell_scan",
+    "k_cellstart_tiles": "cell_scan", "k_gather": "scatter",
+    # the small scans (chunk counts, work lists, seed ranks) are spread over three phases: listed, not attributed
     "k_core": "core_count", "k_core_lds": "core_count", "k_wl_fill": "core_count",
-    "k_union": "union", "k_union_init": "union", "k_flatten0": "union", "k_init_parent": "union",
+    "k_union": "union", "k_union_init": "union", "k_union_init_list": "union", "k_flatten0": "union",
     "k_flatten": "flatten_number", "k_seed_popc": "flatten_number", "k_seedflag": "flatten_number",
     "k_rootk": "flatten_number",
-    "k_labk_rest": "border", "k_border": "border", "k_output": "output",
+    "k_labk_rest": "border", "k_border": "border", "k_border_list": "border",
+    "k_output": "output", "k_out_scatter": "out_scatter", "k_out_write": "out_write",
     "k_icp_pass": "icp", "k_icp_step": "icp", "k_model32": "icp", "k_absmax": "icp",
 }
 
@@ -78,7 +82,8 @@ def main():
         agg[k][0] += int(r["Calls"])
         agg[k][1] += float(r["TotalDurationNs"])
         agg[k][2] += float(r["Percentage"])
-    steps = max(agg.get("k_output", [1])[0], 1)  # launches of the per-step kernels = profiled steps
+    # launches of a once-per-step kernel = profiled steps
+    steps = max(agg.get("k_out_write", agg.get("k_output", [1]))[0], 1)
     for k in order:
         calls, tot, pct = agg[k]
         fz = pmc["FETCH_SIZE"].get(k)

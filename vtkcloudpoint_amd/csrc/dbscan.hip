@@ -1052,24 +1052,27 @@ __global__ __launch_bounds__(TPB) void k_union(const double* __restrict__ sorted
 #undef VCP_FLUSH
 #undef VCP_JOIN
 
-// Phase 2b (with recorded lists): join the flattened phase-1 trees along every RECORDED edge -- list reads, finds and
-// CAS only, no cell walk and no distance test (the list entries are confirmed neighbours).  Most of the merges that the
-// full edge scan of phase 3 would have to discover happen here; after a second flatten phase 3 sees almost only
-// candidates that carry its own root word.  Used in 3-D only (see the launch site).
+// Phase 2b (with recorded lists): the ROOTS of the flattened phase-1 trees join their trees along their recorded edges --
+// list reads, finds and CAS only, no cell walk and no distance test (the entries are confirmed neighbours).  A root is
+// the first point of its tree in position order, so its list reaches into the trees round it: most of the merges the
+// full edge scan of phase 3 would otherwise discover one contended CAS at a time happen here (C4 cloud: the scan kernel
+// drops from 265 to 109 us for 78 us of this round; L2_3D: union phase 1.27 -> 0.58 ms).  Letting EVERY expanding point
+// join along its list was measured too: the scan falls to 87 us but the round itself costs 500 us in 2-D (all trees of
+// a blob hooked at once).
 __global__ __launch_bounds__(TPB) void k_union_list(const uint8_t* __restrict__ flags, uint32_t* __restrict__ parent,
                                                    NbrOut no, WorkList wlE) {
   const uint32_t p = wl_fetch(wlE);
   if (p == NONE) return;
+  uint32_t rp = ld_parent_cached(parent, p);
+  if (rp != p) return;  // roots only
   const int nrec = flags[p] >> 4;
   const uint32_t* li = nbr_list(no, p);
-  uint32_t rp = ld_parent_cached(parent, p);
   // words already known to be in my tree (the forest is flat: every member of a foreign tree shows the same word, so
-  // one join per foreign tree is enough); every undirected edge is taken from its larger endpoint where both ends
-  // recorded it
+  // one join per foreign tree is enough)
   uint32_t s0 = NONE, s1 = NONE, s2 = NONE;
   for (int k = 0; k < nrec; k++) {
     const uint32_t j = li[k];
-    if (j > p || !(flags[j] & F_EXPAND)) continue;
+    if (!(flags[j] & F_EXPAND)) continue;
     const uint32_t x = ld_parent_cached(parent, j);
     if (x == rp || x == s0 || x == s1 || x == s2) continue;
     const uint32_t rx = uf_root(parent, x);
@@ -1856,13 +1859,8 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   if (no.NB > 0) {
     hipLaunchKernelGGL(k_union_init_list, dim3(nbl), dim3(TPB), 0, st, flags, parent, no, wlE);
     hipLaunchKernelGGL(k_flatten0, dim3(nbl), dim3(TPB), 0, st, parent, wlE);
-    // joining along the recorded edges first pays where the full edge scan is expensive: in 3-D (27 cells, hundreds of
-    // candidates per point) the union phase drops from 1.27 to 0.73 ms; in 2-D the scan kernel falls from 265 to 87 us
-    // but the list round itself costs 500 us (all trees of a blob are hooked at once: CAS contention), so 2-D skips it
-    if (GD == 3) {
-      hipLaunchKernelGGL(k_union_list, dim3(nbl), dim3(TPB), 0, st, flags, parent, no, wlE);
-      hipLaunchKernelGGL(k_flatten0, dim3(nbl), dim3(TPB), 0, st, parent, wlE);
-    }
+    hipLaunchKernelGGL(k_union_list, dim3(nbl), dim3(TPB), 0, st, flags, parent, no, wlE);
+    hipLaunchKernelGGL(k_flatten0, dim3(nbl), dim3(TPB), 0, st, parent, wlE);
   } else if (GD == 2) {
     hipLaunchKernelGGL((k_union_init<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup,
                        flags, parent, wlE);

@@ -935,12 +935,41 @@ __global__ __launch_bounds__(TPB) void k_union_init_list(const uint8_t* __restri
   }
 }
 
-// Phase 2: flatten the phase-1 forest (no atomics; a racing reader sees an older or a newer ancestor)
-__global__ __launch_bounds__(TPB) void k_flatten0(uint32_t* __restrict__ parent, WorkList wlE) {
+// Phase 2: flatten the phase-1 forest (no atomics; a racing reader sees an older or a newer ancestor).
+// JOIN (first of the two flatten passes when lists were recorded): a lane that finds itself a ROOT joins its tree along
+// its recorded edges -- list reads, finds and CAS only, no cell walk and no distance test (the entries are confirmed
+// neighbours).  A root is the first point of its tree in position order, so its list reaches into the trees round it:
+// most of the merges the full edge scan of phase 3 would otherwise discover one contended CAS at a time happen here
+// (C4 cloud: the scan kernel drops from 265 to 109 us; L2_3D: union phase 1.27 -> 0.58 ms).  Letting EVERY expanding
+// point join along its list was measured too: the scan falls to 87 us but that round costs 500 us in 2-D (all trees of
+// a blob hooked at once).  The second pass flattens what the joins built.
+template <bool JOIN>
+__global__ __launch_bounds__(TPB) void k_flatten0(uint32_t* __restrict__ parent, WorkList wlE,
+                                                 const uint8_t* __restrict__ flags, NbrOut no) {
   const uint32_t p = wl_fetch(wlE);  // expanding points only (a quarter of the positions here)
   if (p == NONE) return;
   uint32_t r = (uint32_t)p, x = ld_parent_cached(parent, r);
-  if (x == r) return;
+  if (x == r) {
+    if (!JOIN) return;
+    uint32_t rp = p;
+    const int nrec = flags[p] >> 4;
+    const uint32_t* li = nbr_list(no, p);
+    uint32_t s0 = NONE, s1 = NONE, s2 = NONE;  // words already known to be in my tree
+    for (int k = 0; k < nrec; k++) {
+      const uint32_t j = li[k];
+      if (!(flags[j] & F_EXPAND)) continue;
+      const uint32_t y = ld_parent_cached(parent, j);
+      if (y == rp || y == s0 || y == s1 || y == s2) continue;
+      const uint32_t ry = uf_root(parent, y);
+      const uint32_t rm = uf_root(parent, rp);
+      s2 = s1;
+      s1 = s0;
+      s0 = rp;
+      rp = (ry != rm) ? uf_link(parent, rm, ry) : rm;
+      if (y != rp) s1 = y;
+    }
+    return;
+  }
   while (x != r) {
     r = x;
     x = ld_parent_cached(parent, r);
@@ -1051,39 +1080,6 @@ __global__ __launch_bounds__(TPB) void k_union(const double* __restrict__ sorted
 }
 #undef VCP_FLUSH
 #undef VCP_JOIN
-
-// Phase 2b (with recorded lists): the ROOTS of the flattened phase-1 trees join their trees along their recorded edges --
-// list reads, finds and CAS only, no cell walk and no distance test (the entries are confirmed neighbours).  A root is
-// the first point of its tree in position order, so its list reaches into the trees round it: most of the merges the
-// full edge scan of phase 3 would otherwise discover one contended CAS at a time happen here (C4 cloud: the scan kernel
-// drops from 265 to 109 us for 78 us of this round; L2_3D: union phase 1.27 -> 0.58 ms).  Letting EVERY expanding point
-// join along its list was measured too: the scan falls to 87 us but the round itself costs 500 us in 2-D (all trees of
-// a blob hooked at once).
-__global__ __launch_bounds__(TPB) void k_union_list(const uint8_t* __restrict__ flags, uint32_t* __restrict__ parent,
-                                                   NbrOut no, WorkList wlE) {
-  const uint32_t p = wl_fetch(wlE);
-  if (p == NONE) return;
-  uint32_t rp = ld_parent_cached(parent, p);
-  if (rp != p) return;  // roots only
-  const int nrec = flags[p] >> 4;
-  const uint32_t* li = nbr_list(no, p);
-  // words already known to be in my tree (the forest is flat: every member of a foreign tree shows the same word, so
-  // one join per foreign tree is enough)
-  uint32_t s0 = NONE, s1 = NONE, s2 = NONE;
-  for (int k = 0; k < nrec; k++) {
-    const uint32_t j = li[k];
-    if (!(flags[j] & F_EXPAND)) continue;
-    const uint32_t x = ld_parent_cached(parent, j);
-    if (x == rp || x == s0 || x == s1 || x == s2) continue;
-    const uint32_t rx = uf_root(parent, x);
-    const uint32_t rm = uf_root(parent, rp);
-    s2 = s1;
-    s1 = s0;
-    s0 = rp;
-    rp = (rx != rm) ? uf_link(parent, rm, rx) : rm;
-    if (x != rp) s1 = x;
-  }
-}
 
 // flatten + smallest list position per component; lanes of a wave that share a root (the common
 // case inside a blob: the wave covers neighbouring cells) combine before one atomicMin
@@ -1858,13 +1854,12 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   const bool pre = GD == 2 || no.NB > 0;  // with lists the forest costs no search, so it pays in 3-D too
   if (no.NB > 0) {
     hipLaunchKernelGGL(k_union_init_list, dim3(nbl), dim3(TPB), 0, st, flags, parent, no, wlE);
-    hipLaunchKernelGGL(k_flatten0, dim3(nbl), dim3(TPB), 0, st, parent, wlE);
-    hipLaunchKernelGGL(k_union_list, dim3(nbl), dim3(TPB), 0, st, flags, parent, no, wlE);
-    hipLaunchKernelGGL(k_flatten0, dim3(nbl), dim3(TPB), 0, st, parent, wlE);
+    hipLaunchKernelGGL(k_flatten0<true>, dim3(nbl), dim3(TPB), 0, st, parent, wlE, flags, no);
+    hipLaunchKernelGGL(k_flatten0<false>, dim3(nbl), dim3(TPB), 0, st, parent, wlE, flags, no);
   } else if (GD == 2) {
     hipLaunchKernelGGL((k_union_init<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup,
                        flags, parent, wlE);
-    hipLaunchKernelGGL(k_flatten0, dim3(nbl), dim3(TPB), 0, st, parent, wlE);
+    hipLaunchKernelGGL(k_flatten0<false>, dim3(nbl), dim3(TPB), 0, st, parent, wlE, flags, no);
   }
   if (pre)
     hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED, true>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup,

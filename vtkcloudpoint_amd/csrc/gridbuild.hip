@@ -250,7 +250,7 @@ __global__ __launch_bounds__(FT) void k_part_fine(const Rec* __restrict__ rec, c
 // Windows of 2^OWSH list positions: 8192 x (4 + 1 + 1) bytes are assembled in LDS and stored as full lines (0.022 ms for
 // 10 M points, against 0.15 ms for the same stores made straight from the lanes -- tools/micro/part_bench.hip).
 constexpr int OWSH = 13;
-constexpr int OT = 512, OPT = 16;  // scatter pass: OT * OPT positions per workgroup
+constexpr int OT = 1024, OPT = 16;  // scatter pass: OT * OPT positions per workgroup (longer runs per window)
 constexpr int OWT = 512;           // write pass: one workgroup per window
 
 __global__ __launch_bounds__(OT) void k_out_scatter(const uint32_t* __restrict__ sord, const uint32_t* __restrict__ labk,

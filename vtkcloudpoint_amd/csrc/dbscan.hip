@@ -598,10 +598,10 @@ __global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted,
 template <int GD>
 struct CoreTile;
 template <>
-struct CoreTile<2> {  // 3 rows x 512 x 8 B = 12 KB
+struct CoreTile<2> {  // 3 rows x 512 x 8 B = 12 KB (+ slack: a lane's last trip of four may read past its range)
   static constexpr int NR = 3, CAP = 512;
   union {
-    float2 pt[3][512];
+    float2 pt[3][512 + 4];
     uint32_t lout[15 * TPB];  // the neighbour lists are compacted here once the rows have been scanned
   };
   uint32_t lo[3], hi[3];
@@ -754,14 +754,32 @@ __global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sor
         if (cnt >= min_pts || rs[r] >= re[r]) continue;
         const uint32_t lo = t.lo[r];
         const uint32_t e = re[r] - lo, a = rs[r] - lo;
+        // Branch-free trips of four: `in` = provisional hits (value <= hi), `am` = those of them the binary32 value cannot
+        // decide (value > lo); candidates past the lane's range are read (the tile has slack) and masked out.  Only a
+        // trip with an undecided candidate -- rare -- takes the exact binary64 test.
         for (uint32_t j = a; j < e; j += UNR) {
           float c[UNR][3];
 #pragma unroll
-          for (int u = 0; u < UNR; u++) t.get(r, min(j + u, e - 1), c[u]);
-          uint32_t nib = 0;
+          for (int u = 0; u < UNR; u++) t.get(r, j + u, c[u]);
+          uint32_t nib = 0, am = 0;
 #pragma unroll
-          for (int u = 0; u < UNR; u++)
-            nib |= ((j + u < e) && within_scr<GD, METRIC>(qf, c[u], sc, q, sorted, lo + j + u, thr)) ? (1u << u) : 0u;
+          for (int u = 0; u < UNR; u++) {
+            const float v = value32<METRIC>(qf, c[u]);
+            nib |= (v > sc.hi) ? 0u : (1u << u);  // a NaN stays provisional ...
+            am |= (v <= sc.lo) ? 0u : (1u << u);  // ... and undecided
+          }
+          const uint32_t lim = e - j >= (uint32_t)UNR ? 0xFu : ((1u << (e - j)) - 1u);
+          nib &= lim;
+          am &= nib;
+          if (am != 0u) {
+#pragma unroll
+            for (int u = 0; u < UNR; u++)
+              if ((am >> u) & 1u) {
+                double rr[3];
+                load_pt<GD>(sorted, lo + j + u, rr);
+                if (!within<METRIC>(q, rr, thr)) nib &= ~(1u << u);
+              }
+          }
           cnt += __popc(nib);
           const uint32_t sh = j - a;
           hm[r] |= sh < 32u ? nib << sh : 0u;

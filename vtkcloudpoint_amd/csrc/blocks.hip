@@ -30,7 +30,7 @@ struct BlocksState {
   double eps = 0;
   int min_pts = 0, small_max = 3, take = 0;
   double x_Min = 0, x_Max = 0, y_Min = 0, y_Max = 0, cell_x = 0, cell_y = 0;
-  DevBuf motor, pkey, raw, rankpos, blockof, bl, motor_bm, blockstart, gtwice, gnclus, tmp0, tmp1, tmp2, tmp3, sorttmp,
+  DevBuf motor, pkey, orand, raw, rankpos, blockof, bl, motor_bm, blockstart, gtwice, gnclus, tmp0, tmp1, tmp2, tmp3, sorttmp,
       blk_t, csize, cstart, kb, zb, keep, order, newlab, zflag, zlist, zcoords, zlab, misc;
   std::vector<uint32_t> h_blockstart;
   bool ready = false;
@@ -197,15 +197,42 @@ __global__ __launch_bounds__(BT) void k_minmax2_final(const double* __restrict__
 }
 
 // FrmMain.cs:1231-1232: d = Math.Max(x - x_Min, y - y_Min); non-negative, so the IEEE bit pattern orders it
+// Also reduces, per workgroup and into 32 slots, the OR and the AND of all keys: bits on which every key agrees cannot
+// change the order, so the radix sort runs over the varying bit range only (coordinates on a 2^-10 grid below 2^10: 20
+// significant bits -> 3 passes instead of the 8 of a 64-bit key).
 __global__ __launch_bounds__(BT) void k_sortkey(const double* __restrict__ motor, int64_t n, double x_Min, double y_Min,
-                                               uint64_t* __restrict__ key, uint32_t* __restrict__ idx) {
+                                               uint64_t* __restrict__ key, uint32_t* __restrict__ idx,
+                                               unsigned long long* __restrict__ orand) {
   int64_t i = (int64_t)blockIdx.x * BT + threadIdx.x;
-  if (i >= n) return;
-  double2 v = *reinterpret_cast<const double2*>(motor + 2 * i);
-  double a = v.x - x_Min, b = v.y - y_Min;
-  double d = a > b ? a : b;  // Math.Max on finite values
-  key[i] = (uint64_t)__double_as_longlong(d + 0.0);
-  idx[i] = (uint32_t)i;
+  unsigned long long ko = 0ull, ka = ~0ull;
+  if (i < n) {
+    double2 v = *reinterpret_cast<const double2*>(motor + 2 * i);
+    double a = v.x - x_Min, b = v.y - y_Min;
+    double d = a > b ? a : b;  // Math.Max on finite values
+    const uint64_t k = (uint64_t)__double_as_longlong(d + 0.0);
+    key[i] = k;
+    idx[i] = (uint32_t)i;
+    ko = ka = k;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    ko |= __shfl_xor(ko, d, 64);
+    ka &= __shfl_xor(ka, d, 64);
+  }
+  __shared__ unsigned long long so[BT / 64], sa[BT / 64];
+  if ((threadIdx.x & 63) == 0) {
+    so[threadIdx.x >> 6] = ko;
+    sa[threadIdx.x >> 6] = ka;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < BT / 64; k++) {
+      so[0] |= so[k];
+      sa[0] &= sa[k];
+    }
+    atomicOr(&orand[blockIdx.x & 31], so[0]);
+    atomicAnd(&orand[32 + (blockIdx.x & 31)], sa[0]);
+  }
 }
 
 __global__ __launch_bounds__(BT) void k_inverse(const uint32_t* __restrict__ perm, int64_t n, uint32_t* __restrict__ inv) {
@@ -288,7 +315,8 @@ __global__ __launch_bounds__(BT) void k_gather_motor(const double* __restrict__ 
 // per block: K_b = max local id, Z_b = number of noise points.  One wave per block walks the block's slice of
 // the block-major label list (coalesced) and reduces in registers: no atomics.
 __global__ __launch_bounds__(BT) void k_block_stats(const int32_t* __restrict__ local, const uint32_t* __restrict__ blockstart,
-                                                   int64_t nblocks, uint32_t* __restrict__ kb, uint32_t* __restrict__ zb) {
+                                                   int64_t nblocks, uint32_t* __restrict__ kb, uint32_t* __restrict__ zb,
+                                                   uint32_t* __restrict__ kmax_slots) {
   const int64_t b = (int64_t)blockIdx.x * (BT / 64) + (threadIdx.x >> 6);
   if (b >= nblocks) return;
   const int lane = threadIdx.x & 63;
@@ -306,6 +334,9 @@ __global__ __launch_bounds__(BT) void k_block_stats(const int32_t* __restrict__ 
   if (lane == 0) {
     kb[b] = K;
     zb[b] = Z;
+    // largest local id over all blocks (32 slots: a single word would serialise 27 k atomics): the key width of the
+    // final (block, local id) sort
+    if (K > kmax_slots[blockIdx.x & 31]) atomicMax(&kmax_slots[blockIdx.x & 31], K);
   }
 }
 // cluster sizes: one wave per block counts its local ids in LDS (a block holds ~ptsInCell points, so few ids);
@@ -494,10 +525,39 @@ int blocks_begin(vcp_ctx* ctx, const double* d_motor_in, bool from_host, const d
   VCP_TRY(ens(ctx, s->tmp2, (size_t)n * 4));
   VCP_TRY(ens(ctx, s->raw, (size_t)n * 4));
   VCP_TRY(ens(ctx, s->rankpos, (size_t)n * 4));
+  VCP_TRY(ens(ctx, s->orand, 64 * 8));
+  unsigned long long* orand = s->orand.as<unsigned long long>();
+  VCP_HIP(ctx, hipMemsetAsync(orand, 0, 32 * 8, st));
+  VCP_HIP(ctx, hipMemsetAsync(orand + 32, 0xFF, 32 * 8, st));
   hipLaunchKernelGGL(k_sortkey, dim3(nblk(n)), dim3(BT), 0, st, motor, n, s->x_Min, s->y_Min, s->tmp0.as<uint64_t>(),
-                     s->tmp2.as<uint32_t>());
-  VCP_TRY(sort_pairs(ctx, s, s->tmp0.as<uint64_t>(), s->tmp1.as<uint64_t>(), s->tmp2.as<uint32_t>(),
-                     s->raw.as<uint32_t>(), (size_t)n, 64));
+                     s->tmp2.as<uint32_t>(), orand);
+  int bit_lo = 0, bit_hi = 64;
+  {
+    unsigned long long* ho = reinterpret_cast<unsigned long long*>(ctx->pinned) + 256;
+    VCP_HIP(ctx, hipMemcpyAsync(ho, orand, 64 * 8, hipMemcpyDeviceToHost, st));
+    VCP_HIP(ctx, hipStreamSynchronize(st));
+    unsigned long long o = 0ull, a = ~0ull;
+    for (int k = 0; k < 32; k++) {
+      o |= ho[k];
+      a &= ho[32 + k];
+    }
+    const unsigned long long varying = o & ~a;
+    if (varying == 0ull) {
+      bit_lo = 0;
+      bit_hi = 1;  // all keys equal: one pass keeps the input order
+    } else {
+      bit_lo = __builtin_ctzll(varying);
+      bit_hi = 64 - __builtin_clzll(varying);
+    }
+  }
+  {
+    size_t tb = 0;
+    VCP_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, s->tmp0.as<uint64_t>(), s->tmp1.as<uint64_t>(),
+                                           s->tmp2.as<uint32_t>(), s->raw.as<uint32_t>(), (size_t)n, bit_lo, bit_hi, st));
+    VCP_TRY(ens(ctx, s->sorttmp, tb + 64));
+    VCP_HIP(ctx, rocprim::radix_sort_pairs(s->sorttmp.p, tb, s->tmp0.as<uint64_t>(), s->tmp1.as<uint64_t>(),
+                                           s->tmp2.as<uint32_t>(), s->raw.as<uint32_t>(), (size_t)n, bit_lo, bit_hi, st));
+  }
   hipLaunchKernelGGL(k_inverse, dim3(nblk(n)), dim3(BT), 0, st, s->raw.as<uint32_t>(), n, s->rankpos.as<uint32_t>());
   // first block -> block size (FrmMain.cs:1253-1258)
   s->take = (int)std::min<int64_t>(pts_in_cell, n);
@@ -594,14 +654,16 @@ int blocks_finish(vcp_ctx* ctx, const int32_t* d_local, int64_t evals_blocks, in
   uint32_t* cstart = s->cstart.as<uint32_t>();
   uint32_t* dmisc = s->misc.as<uint32_t>();  // [0] total clusters, [1] kept, [2] err, [3] Z
   const unsigned nbw = (unsigned)((nb + BT / 64 - 1) / (BT / 64));  // one wave per block
-  VCP_HIP(ctx, hipMemsetAsync(dmisc, 0, 64, st));
+  VCP_HIP(ctx, hipMemsetAsync(dmisc, 0, 64 * 4, st));  // [8..40): slots of the largest local id
   VCP_HIP(ctx, hipMemsetAsync(kb + nb, 0, 8, st));  // the scan reads kb[nb]
-  hipLaunchKernelGGL(k_block_stats, dim3(nbw), dim3(BT), 0, st, d_local, blockstart, nb, kb, zb);
+  hipLaunchKernelGGL(k_block_stats, dim3(nbw), dim3(BT), 0, st, d_local, blockstart, nb, kb, zb, dmisc + 8);
   VCP_TRY(vcp_exclusive_scan_u32(ctx, kb, cstart, nb + 1, dmisc));  // cstart[nb] = total clusters
   uint32_t* hp = reinterpret_cast<uint32_t*>(ctx->pinned);
-  VCP_HIP(ctx, hipMemcpyAsync(hp, dmisc, 16, hipMemcpyDeviceToHost, st));
+  VCP_HIP(ctx, hipMemcpyAsync(hp, dmisc, 40 * 4, hipMemcpyDeviceToHost, st));
   VCP_HIP(ctx, hipStreamSynchronize(st));
   const uint32_t totalC = hp[0];
+  uint32_t maxK = 0;  // largest local cluster id in any block
+  for (int k = 0; k < 32; k++) maxK = std::max(maxK, hp[8 + k]);
   VCP_TRY(ens(ctx, s->csize, (size_t)(totalC + 2) * 4));
   VCP_TRY(ens(ctx, s->keep, (size_t)(totalC + 2) * 4 * 2));
   VCP_TRY(ens(ctx, s->tmp3, (size_t)(nb + 2) * 4));
@@ -629,11 +691,6 @@ int blocks_finish(vcp_ctx* ctx, const int32_t* d_local, int64_t evals_blocks, in
   uint32_t* v1o = s->tmp1.as<uint32_t>();
   uint32_t* k2 = v1o + (m + 1);
   uint32_t* order = s->order.as<uint32_t>();
-  uint32_t maxK = 0;
-  {
-    // largest local id (for the key width): read back kb max via the cluster total bound
-    maxK = totalC;  // K_b <= total clusters; only the bit width matters
-  }
   if (m > 0) {
     hipLaunchKernelGGL(k_iota, dim3(nblk(m)), dim3(BT), 0, st, iota, m);
     VCP_HIP(ctx, hipMemcpyAsync(k1, d_local, (size_t)m * 4, hipMemcpyDeviceToDevice, st));
@@ -689,7 +746,7 @@ extern "C" {
 void vcp_blocks_state_free(vcp_ctx* ctx) {
   if (!ctx || !ctx->blocks) return;
   BlocksState* s = ctx->blocks;
-  DevBuf* all[] = {&s->motor, &s->pkey, &s->raw, &s->rankpos, &s->blockof, &s->bl, &s->motor_bm, &s->blockstart,
+  DevBuf* all[] = {&s->motor, &s->pkey, &s->orand, &s->raw, &s->rankpos, &s->blockof, &s->bl, &s->motor_bm, &s->blockstart,
                    &s->gtwice, &s->gnclus, &s->tmp0, &s->tmp1, &s->tmp2, &s->tmp3, &s->sorttmp, &s->blk_t, &s->csize,
                    &s->cstart, &s->kb, &s->zb, &s->keep, &s->order, &s->newlab, &s->zflag, &s->zlist, &s->zcoords,
                    &s->zlab, &s->misc};

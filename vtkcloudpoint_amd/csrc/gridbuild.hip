@@ -144,14 +144,47 @@ __global__ __launch_bounds__(PT) void k_part_scatter(const double* __restrict__ 
 // one pad word per 32 counters: a thread's run of consecutive counters in the scan then walks all banks
 __device__ __forceinline__ uint32_t padded(uint32_t i) { return i + (i >> 5); }
 
-// One workgroup per bucket.  LDS: the bucket's cell counters, then (behind them) the staging area of WCAP records.
-// A bucket of up to WCAP records is placed in LDS in its final order and stored with consecutive lanes on consecutive
-// addresses; a larger one (the dense heart of a cluster) stores every record straight to its slot.
+// One workgroup per bucket.  LDS: the bucket's cell counters, then (behind them) a staging area of WCAP records.
+// Every bucket is assembled in LDS in its final order and stored with consecutive lanes on consecutive addresses (a
+// scattered 16-byte store per record was measured 7x slower than the same bytes as full lines).  A bucket of up to
+// WCAP records takes one window: the scanned counters serve as per-cell cursors.  A larger one (dense clouds, the heart
+// of a cluster) keeps, from the counting pass, each record's RANK inside its cell (rk, 4 B per record), so that its
+// final position start[cell] + rank is known without a cursor, and walks its records once per window of WCAP
+// positions (the records of a bucket stay L2-resident).
 template <int GD, bool GROUPED>
-__global__ __launch_bounds__(FT) void k_part_fine(const Rec* __restrict__ rec, const uint32_t* __restrict__ base,
-                                                 const uint32_t* __restrict__ total, uint32_t nchunk, uint32_t B,
-                                                 uint32_t csh, GridP g, const uint32_t* __restrict__ ord,
-                                                 const uint8_t* __restrict__ in_classed,
+__device__ __forceinline__ void fine_flush(uint32_t s0, uint32_t m, const double* sxy, const uint32_t* sidx, const GridP& g,
+                                           const uint32_t* __restrict__ ord, const uint8_t* __restrict__ in_classed,
+                                           const int32_t* __restrict__ group, double* __restrict__ sorted,
+                                           float* __restrict__ sorted32, uint32_t* __restrict__ sord,
+                                           int32_t* __restrict__ sgroup, uint8_t* __restrict__ flags,
+                                           uint32_t* __restrict__ pos) {
+  if (GD == 2) {
+    const double2* src = reinterpret_cast<const double2*>(sxy);
+    double2* dst = reinterpret_cast<double2*>(sorted) + s0;
+    float2* dst32 = reinterpret_cast<float2*>(sorted32) + s0;
+    for (uint32_t k = threadIdx.x; k < m; k += FT) {
+      const double2 v = src[k];
+      dst[k] = v;
+      dst32[k] = make_float2((float)(v.x - g.mn[0]), (float)(v.y - g.mn[1]));
+    }
+  } else {
+    for (uint32_t k = threadIdx.x; k < 3 * m; k += FT) sorted[(size_t)3 * s0 + k] = sxy[k];
+    for (uint32_t k = threadIdx.x; k < m; k += FT) store_pt32<GD>(sorted32, (int64_t)s0 + k, sxy + (size_t)3 * k, g);
+  }
+  for (uint32_t k = threadIdx.x; k < m; k += FT) {
+    const uint32_t i = sidx[k], p = s0 + k;
+    sord[p] = ord ? ord[i] : i;
+    if (GROUPED) sgroup[p] = group[i];
+    if (in_classed) flags[p] = in_classed[i] ? F_CLASSED : 0;
+    if (pos) pos[i] = p;
+  }
+}
+
+template <int GD, bool GROUPED>
+__global__ __launch_bounds__(FT) void k_part_fine(const Rec* __restrict__ rec, uint32_t* __restrict__ rk,
+                                                 const uint32_t* __restrict__ base, const uint32_t* __restrict__ total,
+                                                 uint32_t nchunk, uint32_t B, uint32_t csh, GridP g,
+                                                 const uint32_t* __restrict__ ord, const uint8_t* __restrict__ in_classed,
                                                  const int32_t* __restrict__ group, uint32_t* __restrict__ cellstart,
                                                  double* __restrict__ sorted, float* __restrict__ sorted32,
                                                  uint32_t* __restrict__ sord, int32_t* __restrict__ sgroup,
@@ -167,13 +200,17 @@ __global__ __launch_bounds__(FT) void k_part_fine(const Rec* __restrict__ rec, c
   const uint32_t c0 = b << csh;
   const uint32_t s = base[(size_t)b * nchunk];
   const uint32_t e = (b + 1 < B) ? base[(size_t)(b + 1) * nchunk] : *total;
+  const uint32_t m = e - s;
+  const bool big = m > WCAP;
   for (uint32_t k = threadIdx.x; k < padded(CPB); k += FT) cnt[k] = 0;
   __syncthreads();
   for (uint32_t j = s + threadIdx.x; j < e; j += FT) {
     double q[3];
     int cc[3];
     rec_load<GD>(rec, j, q);
-    atomicAdd(&cnt[padded(cell_of<GD>(q, g, cc) - c0)], 1u);
+    uint32_t* slot = &cnt[padded(cell_of<GD>(q, g, cc) - c0)];
+    if (big) rk[j] = atomicAdd(slot, 1u);  // rank inside the cell
+    else atomicAdd(slot, 1u);
   }
   __syncthreads();
   // exclusive scan of the CPB counters, offset by the bucket's first position: thread t owns PER consecutive ones
@@ -202,47 +239,35 @@ __global__ __launch_bounds__(FT) void k_part_fine(const Rec* __restrict__ rec, c
   for (uint32_t k = threadIdx.x; k < CPB; k += FT)
     if (c0 + k <= g.ncells) cellstart[c0 + k] = cnt[padded(k)];
   __syncthreads();
-  // place the records: the scanned counters now serve as per-cell cursors
-  const bool staged = e - s <= WCAP;
-  for (uint32_t j = s + threadIdx.x; j < e; j += FT) {
-    double q[3];
-    int cc[3];
-    const uint32_t i = rec_load<GD>(rec, j, q);
-    const uint32_t p = atomicAdd(&cnt[padded(cell_of<GD>(q, g, cc) - c0)], 1u);
-    if (staged) {
-      store_pt<GD>(sxy, p - s, q);
-      sidx[p - s] = i;
-    } else {
-      store_pt<GD>(sorted, p, q);
-      store_pt32<GD>(sorted32, p, q, g);
-      sord[p] = ord ? ord[i] : i;
-      if (GROUPED) sgroup[p] = group[i];
-      if (in_classed) flags[p] = in_classed[i] ? F_CLASSED : 0;
-      if (pos) pos[i] = p;
+  if (!big) {
+    // one window: the scanned counters serve as per-cell cursors
+    for (uint32_t j = s + threadIdx.x; j < e; j += FT) {
+      double q[3];
+      int cc[3];
+      const uint32_t i = rec_load<GD>(rec, j, q);
+      const uint32_t p = atomicAdd(&cnt[padded(cell_of<GD>(q, g, cc) - c0)], 1u) - s;
+      store_pt<GD>(sxy, p, q);
+      sidx[p] = i;
     }
+    __syncthreads();
+    fine_flush<GD, GROUPED>(s, m, sxy, sidx, g, ord, in_classed, group, sorted, sorted32, sord, sgroup, flags, pos);
+    return;
   }
-  if (!staged) return;
-  __syncthreads();
-  const uint32_t m = e - s;
-  if (GD == 2) {
-    const double2* src = reinterpret_cast<const double2*>(sxy);
-    double2* dst = reinterpret_cast<double2*>(sorted) + s;
-    float2* dst32 = reinterpret_cast<float2*>(sorted32) + s;
-    for (uint32_t k = threadIdx.x; k < m; k += FT) {
-      const double2 v = src[k];
-      dst[k] = v;
-      dst32[k] = make_float2((float)(v.x - g.mn[0]), (float)(v.y - g.mn[1]));
+  for (uint32_t w0 = 0; w0 < m; w0 += WCAP) {
+    for (uint32_t j = s + threadIdx.x; j < e; j += FT) {
+      double q[3];
+      int cc[3];
+      const uint32_t i = rec_load<GD>(rec, j, q);
+      const uint32_t p = cnt[padded(cell_of<GD>(q, g, cc) - c0)] + rk[j] - s - w0;  // wraps below the window
+      if (p < WCAP) {
+        store_pt<GD>(sxy, p, q);
+        sidx[p] = i;
+      }
     }
-  } else {
-    for (uint32_t k = threadIdx.x; k < 3 * m; k += FT) sorted[(size_t)3 * s + k] = sxy[k];
-    for (uint32_t k = threadIdx.x; k < m; k += FT) store_pt32<GD>(sorted32, (int64_t)s + k, sxy + (size_t)3 * k, g);
-  }
-  for (uint32_t k = threadIdx.x; k < m; k += FT) {
-    const uint32_t i = sidx[k], p = s + k;
-    sord[p] = ord ? ord[i] : i;
-    if (GROUPED) sgroup[p] = group[i];
-    if (in_classed) flags[p] = in_classed[i] ? F_CLASSED : 0;
-    if (pos) pos[i] = p;
+    __syncthreads();
+    fine_flush<GD, GROUPED>(s + w0, min(WCAP, m - w0), sxy, sidx, g, ord, in_classed, group, sorted, sorted32, sord, sgroup,
+                            flags, pos);
+    __syncthreads();
   }
 }
 
@@ -372,7 +397,9 @@ int build(vcp_ctx* ctx, const GridBuildArgs& a) {
   hipLaunchKernelGGL((k_part_scatter<GD, GROUPED>), dim3(pg.nchunk), dim3(PT), lds_h, st, a.d_coords, a.n, a.stride, a.g,
                      a.d_group, a.glo, a.ghi, pg.csh, pg.B, pg.chunk, pg.nchunk, counts, rec, a.pos);
   vcp_phase(ctx, "part_fine");
-  hipLaunchKernelGGL((k_part_fine<GD, GROUPED>), dim3(pg.B), dim3(FT), lds_f, st, rec, counts, total, pg.nchunk, pg.B,
+  VCP_TRY(vcp_ensure(ctx, ctx->b_rank, (size_t)a.n * 4));  // ranks inside the cell, written for large buckets only
+  hipLaunchKernelGGL((k_part_fine<GD, GROUPED>), dim3(pg.B), dim3(FT), lds_f, st, rec, ctx->b_rank.as<uint32_t>(), counts,
+                     total, pg.nchunk, pg.B,
                      pg.csh, a.g, a.d_ord, a.d_in_classed, a.d_group, a.cellstart, a.sorted, a.sorted32, a.sord, a.sgroup,
                      a.flags, a.pos);
   VCP_HIP(ctx, hipGetLastError());

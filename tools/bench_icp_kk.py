@@ -23,3 +23,11 @@ for K in (4000, 27380):
         e = time.perf_counter() - t
         best = e if best is None else min(best, e)
     print("K=%d: %.2f ms, %d rounds, rmse %.2e" % (K, best * 1e3, r["iters"], r["rmse"]), flush=True)
+    M = np.eye(4)
+    best = None
+    for _ in range(6):
+        t = time.perf_counter()
+        m = ctx.match(cen, truth, M, 0.5)
+        e = time.perf_counter() - t
+        best = e if best is None else min(best, e)
+    print("K=%d: match %.3f ms" % (K, best * 1e3), flush=True)

@@ -136,8 +136,11 @@ __global__ __launch_bounds__(TB) void k_icp_pass(const double* __restrict__ mode
   double s[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) s[k] = 0.0;
-  for (int64_t base = (int64_t)blockIdx.x * TB; base < nd; base += (int64_t)gridDim.x * TB) {  // uniform trip count
-    const int64_t i = base + threadIdx.x;
+  // GRID: nng::NNG consecutive lanes work one data point (they split the rows of its search block)
+  constexpr int LPQ = GRID ? nng::NNG : 1;
+  const int sub = GRID ? (int)(threadIdx.x & (LPQ - 1)) : 0;
+  for (int64_t base = (int64_t)blockIdx.x * TB; base < nd * LPQ; base += (int64_t)gridDim.x * TB) {  // uniform trip count
+    const int64_t i = (base + threadIdx.x) / LPQ;
     const bool live = i < nd;
     const int64_t il = live ? i : nd - 1;  // idle lanes of the last workgroup recompute the last point, unused
     const double d0 = data[3 * il], d1 = data[3 * il + 1], d2 = data[3 * il + 2];
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(TB) void k_icp_pass(const double* __restrict__ mode
     int order = 0;
     if (GRID) {
       double bestv;
-      nng::query<false>(ng, p, order, bestv);
+      nng::query<false>(ng, p, sub, order, bestv);
     } else {
     const double pc0 = p[0] - cen0, pc1 = p[1] - cen1, pc2 = p[2] - cen2;
     const float q0 = (float)pc0, q1 = (float)pc1, q2 = (float)pc2;
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(TB) void k_icp_pass(const double* __restrict__ mode
       }
     }
     }  // !GRID
-    if (!live) continue;
+    if (!live || sub != 0) continue;  // one lane of the group carries the point into the sums
     if (nn) nn[i] = order;
     const double y0 = model[3 * order], y1 = model[3 * order + 1], y2 = model[3 * order + 2];
     const double y[3] = {y0, y1, y2};
@@ -499,7 +502,7 @@ int icp_run(vcp_ctx* ctx, const double* d_model, int64_t nm, const double* d_dat
             double tol, int stop_rule, int max_iter, int mode, IcpState* out, int32_t* d_nn) {
   hipStream_t st = ctx->stream;
   // small data sets: one wave per workgroup so that they reach more CUs; large models: LDS tiles
-  const bool small = nd <= (int64_t)64 * ICP_MAX_BLOCKS;
+  const bool small0 = nd <= (int64_t)64 * ICP_MAX_BLOCKS;
   // models beyond the scalar cache: binned once per call (they do not move), grid search per data point; a model with
   // non-finite coordinates keeps the LDS-tiled full scan
   NNGrid ng{};
@@ -510,8 +513,9 @@ int icp_run(vcp_ctx* ctx, const double* d_model, int64_t nm, const double* d_dat
     else if (grc != VCP_ERR_UNSUPPORTED) return grc;
   }
   const bool tiled = nm > 512 && !grid;
+  const bool small = grid ? nd * nng::NNG <= (int64_t)64 * ICP_MAX_BLOCKS : small0;
   const int tb = small ? 64 : ITPB;
-  const int nb = (int)vcp_blocks(nd, tb, ICP_MAX_BLOCKS);
+  const int nb = (int)vcp_blocks(grid ? nd * nng::NNG : nd, tb, ICP_MAX_BLOCKS);
   VCP_TRY(vcp_ensure(ctx, ctx->b_icp_part, (size_t)ICP_MAX_BLOCKS * 16 * sizeof(double) + sizeof(IcpState) + 256));
   VCP_TRY(vcp_ensure(ctx, ctx->b_aux0, (size_t)nm * sizeof(float4) + 64));
   double* part = ctx->b_icp_part.as<double>();
@@ -520,8 +524,10 @@ int icp_run(vcp_ctx* ctx, const double* d_model, int64_t nm, const double* d_dat
   IcpState* h_st = reinterpret_cast<IcpState*>(ctx->pinned);
   *h_st = init;
   VCP_HIP(ctx, hipMemcpyAsync(d_st, h_st, sizeof(IcpState), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_model_frame, dim3(1), dim3(ITPB), 0, st, d_model, nm, d_st);
-  hipLaunchKernelGGL(k_model32, dim3(vcp_blocks(nm, ITPB)), dim3(ITPB), 0, st, d_model, nm, d_st, model32);
+  if (!grid) {  // the binary32 screening frame and copy serve the full scans only
+    hipLaunchKernelGGL(k_model_frame, dim3(1), dim3(ITPB), 0, st, d_model, nm, d_st);
+    hipLaunchKernelGGL(k_model32, dim3(vcp_blocks(nm, ITPB)), dim3(ITPB), 0, st, d_model, nm, d_st, model32);
+  }
   int launched = 0;
   for (;;) {
     const int batch = mode == MODE_SUMS_ONLY ? 1 : std::min(ICP_BATCH, max_iter - launched);

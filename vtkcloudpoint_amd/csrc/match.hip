@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "nngrid.hpp"
+#include <cstring>
 #include "vcp_ctx.hpp"
 
 namespace {
@@ -25,14 +26,16 @@ __global__ __launch_bounds__(MT) void k_match(const double* __restrict__ centers
                                              int T, M16 M, double max_dist, double* __restrict__ mxyz,
                                              uint8_t* __restrict__ is_matched, int32_t* __restrict__ nearest,
                                              double* __restrict__ ndist, uint32_t* __restrict__ count, NNGrid ng) {
-  int j = blockIdx.x * MT + threadIdx.x;
+  constexpr int LPQ = GRID ? nng::NNG : 1;  // lanes per centroid (they split the rows of its search block)
+  const int j = (int)(((int64_t)blockIdx.x * MT + threadIdx.x) / LPQ);
+  const int sub = (int)(threadIdx.x & (LPQ - 1));
   bool hit = false;
   if (j < K) {
     const double c0 = centers[3 * j], c1 = centers[3 * j + 1], c2 = centers[3 * j + 2];
     double m[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) m[r] = c0 * M.m[4 * r] + c1 * M.m[4 * r + 1] + c2 * M.m[4 * r + 2] + M.m[4 * r + 3];
-    if (mxyz) {
+    if (mxyz && sub == 0) {
       mxyz[3 * j] = m[0];
       mxyz[3 * j + 1] = m[1];
       mxyz[3 * j + 2] = m[2];
@@ -40,7 +43,7 @@ __global__ __launch_bounds__(MT) void k_match(const double* __restrict__ centers
     int best = 0;
     double bd;
     if (GRID) {
-      nng::query<true>(ng, m, best, bd);
+      nng::query<true>(ng, m, sub, best, bd);
       // the distance the C# holds for the winner (NaN / infinity included: the query only orders finite values)
       double dx = truths[3 * best] - m[0], dy = truths[3 * best + 1] - m[1], dz = truths[3 * best + 2] - m[2];
       bd = sqrt(dx * dx + dy * dy + dz * dz);
@@ -58,10 +61,12 @@ __global__ __launch_bounds__(MT) void k_match(const double* __restrict__ centers
         }
       }
     }
-    nearest[j] = best;
-    if (ndist) ndist[j] = bd;
-    hit = bd < max_dist;
-    is_matched[j] = hit ? 1 : 0;
+    hit = bd < max_dist && sub == 0;
+    if (sub == 0) {
+      nearest[j] = best;
+      if (ndist) ndist[j] = bd;
+      is_matched[j] = hit ? 1 : 0;
+    }
   }
   unsigned long long b = __ballot(hit);
   if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (uint32_t)__popcll(b));
@@ -277,16 +282,28 @@ extern "C" int vcp_match(vcp_ctx* ctx, const double* centers, int32_t K, const d
   if (!centers || !truths || !is_matched || !nearest) return vcp_fail(ctx, VCP_ERR_ARG, "null buffer");
   VCP_TRY(vcp_bind(ctx));
   hipStream_t st = ctx->stream;
-  VCP_TRY(vcp_ensure(ctx, ctx->b_in0, (size_t)K * 24));
-  VCP_TRY(vcp_ensure(ctx, ctx->b_in2, (size_t)T * 24));
-  VCP_TRY(vcp_ensure(ctx, ctx->b_out0, (size_t)K * 24));
-  VCP_TRY(vcp_ensure(ctx, ctx->b_out1, (size_t)K));
-  VCP_TRY(vcp_ensure(ctx, ctx->b_out2, (size_t)K * 8));
-  VCP_TRY(vcp_ensure(ctx, ctx->b_out3, (size_t)K * 4 + 64));
-  VCP_HIP(ctx, hipMemcpyAsync(ctx->b_in0.p, centers, (size_t)K * 24, hipMemcpyHostToDevice, st));
-  VCP_HIP(ctx, hipMemcpyAsync(ctx->b_in2.p, truths, (size_t)T * 24, hipMemcpyHostToDevice, st));
-  uint32_t* cnt = reinterpret_cast<uint32_t*>(ctx->b_out3.as<char>() + (size_t)K * 4);
-  cnt = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(cnt) + 15) & ~(uintptr_t)15);
+  // device layout: [centers K*24 | truths T*24] in b_in0, [xyz K*24 | dist K*8 | nearest K*4 | count 16 | flags K] in
+  // b_out0 -- one copy each way through the pinned stage (the caller's arrays are pageable: five or six separate
+  // copies from/to them cost more than the search itself)
+  const size_t in_c = 0, in_t = (size_t)K * 24, in_bytes = in_t + (size_t)T * 24;
+  const size_t o_xyz = 0, o_dist = (size_t)K * 24, o_near = o_dist + (size_t)K * 8;
+  const size_t o_cnt = (o_near + (size_t)K * 4 + 15) & ~(size_t)15, o_flag = o_cnt + 16, out_bytes = o_flag + (size_t)K;
+  VCP_TRY(vcp_ensure(ctx, ctx->b_in0, in_bytes));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_out0, out_bytes));
+  char* din = ctx->b_in0.as<char>();
+  char* dout = ctx->b_out0.as<char>();
+  char* stage = static_cast<char*>(vcp_stage(ctx, std::max(in_bytes, out_bytes)));
+  if (stage) {
+    std::memcpy(stage + in_c, centers, (size_t)K * 24);
+    std::memcpy(stage + in_t, truths, (size_t)T * 24);
+    VCP_HIP(ctx, hipMemcpyAsync(din, stage, in_bytes, hipMemcpyHostToDevice, st));
+  } else {
+    VCP_HIP(ctx, hipMemcpyAsync(din + in_c, centers, (size_t)K * 24, hipMemcpyHostToDevice, st));
+    VCP_HIP(ctx, hipMemcpyAsync(din + in_t, truths, (size_t)T * 24, hipMemcpyHostToDevice, st));
+  }
+  const double* d_cen = reinterpret_cast<const double*>(din + in_c);
+  const double* d_tru = reinterpret_cast<const double*>(din + in_t);
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(dout + o_cnt);
   VCP_HIP(ctx, hipMemsetAsync(cnt, 0, 16, st));
   M16 m;
   for (int i = 0; i < 16; i++) m.m[i] = M[i];
@@ -295,26 +312,38 @@ extern "C" int vcp_match(vcp_ctx* ctx, const double* centers, int32_t K, const d
   NNGrid ng{};
   bool grid = false;
   if (T > 512) {
-    const int grc = vcp_nngrid_build(ctx, ctx->b_in2.as<double>(), T, &ng);
+    const int grc = vcp_nngrid_build(ctx, d_tru, T, &ng);
     if (grc == VCP_OK) grid = true;
     else if (grc != VCP_ERR_UNSUPPORTED) return grc;
   }
+  double* o_x = reinterpret_cast<double*>(dout + o_xyz);
+  uint8_t* o_f = reinterpret_cast<uint8_t*>(dout + o_flag);
+  int32_t* o_n = reinterpret_cast<int32_t*>(dout + o_near);
+  double* o_d = reinterpret_cast<double*>(dout + o_dist);
   if (grid)
-    hipLaunchKernelGGL(k_match<true>, dim3(vcp_blocks(K, MT)), dim3(MT), 0, st, ctx->b_in0.as<double>(), K,
-                       ctx->b_in2.as<double>(), T, m, max_dist, ctx->b_out0.as<double>(), ctx->b_out1.as<uint8_t>(),
-                       ctx->b_out3.as<int32_t>(), ctx->b_out2.as<double>(), cnt, ng);
+    hipLaunchKernelGGL(k_match<true>, dim3(vcp_blocks((int64_t)K * nng::NNG, MT)), dim3(MT), 0, st, d_cen, K, d_tru, T, m,
+                       max_dist, o_x, o_f, o_n, o_d, cnt, ng);
   else
-    hipLaunchKernelGGL(k_match<false>, dim3(vcp_blocks(K, MT)), dim3(MT), 0, st, ctx->b_in0.as<double>(), K,
-                       ctx->b_in2.as<double>(), T, m, max_dist, ctx->b_out0.as<double>(), ctx->b_out1.as<uint8_t>(),
-                       ctx->b_out3.as<int32_t>(), ctx->b_out2.as<double>(), cnt, ng);
+    hipLaunchKernelGGL(k_match<false>, dim3(vcp_blocks(K, MT)), dim3(MT), 0, st, d_cen, K, d_tru, T, m, max_dist, o_x,
+                       o_f, o_n, o_d, cnt, ng);
   VCP_HIP(ctx, hipGetLastError());
   uint32_t* hp = reinterpret_cast<uint32_t*>(ctx->pinned);
-  if (matched_xyz) VCP_HIP(ctx, hipMemcpyAsync(matched_xyz, ctx->b_out0.p, (size_t)K * 24, hipMemcpyDeviceToHost, st));
-  VCP_HIP(ctx, hipMemcpyAsync(is_matched, ctx->b_out1.p, (size_t)K, hipMemcpyDeviceToHost, st));
-  VCP_HIP(ctx, hipMemcpyAsync(nearest, ctx->b_out3.p, (size_t)K * 4, hipMemcpyDeviceToHost, st));
-  if (nearest_dist) VCP_HIP(ctx, hipMemcpyAsync(nearest_dist, ctx->b_out2.p, (size_t)K * 8, hipMemcpyDeviceToHost, st));
-  VCP_HIP(ctx, hipMemcpyAsync(hp, cnt, 4, hipMemcpyDeviceToHost, st));
-  VCP_HIP(ctx, hipStreamSynchronize(st));
+  if (stage) {
+    VCP_HIP(ctx, hipMemcpyAsync(stage, dout, out_bytes, hipMemcpyDeviceToHost, st));
+    VCP_HIP(ctx, hipStreamSynchronize(st));
+    if (matched_xyz) std::memcpy(matched_xyz, stage + o_xyz, (size_t)K * 24);
+    std::memcpy(is_matched, stage + o_flag, (size_t)K);
+    std::memcpy(nearest, stage + o_near, (size_t)K * 4);
+    if (nearest_dist) std::memcpy(nearest_dist, stage + o_dist, (size_t)K * 8);
+    hp[0] = *reinterpret_cast<const uint32_t*>(stage + o_cnt);
+  } else {
+    if (matched_xyz) VCP_HIP(ctx, hipMemcpyAsync(matched_xyz, o_x, (size_t)K * 24, hipMemcpyDeviceToHost, st));
+    VCP_HIP(ctx, hipMemcpyAsync(is_matched, o_f, (size_t)K, hipMemcpyDeviceToHost, st));
+    VCP_HIP(ctx, hipMemcpyAsync(nearest, o_n, (size_t)K * 4, hipMemcpyDeviceToHost, st));
+    if (nearest_dist) VCP_HIP(ctx, hipMemcpyAsync(nearest_dist, o_d, (size_t)K * 8, hipMemcpyDeviceToHost, st));
+    VCP_HIP(ctx, hipMemcpyAsync(hp, cnt, 4, hipMemcpyDeviceToHost, st));
+    VCP_HIP(ctx, hipStreamSynchronize(st));
+  }
   if (count_matched) *count_matched = (int32_t)hp[0];
   return VCP_OK;
 }

@@ -2,6 +2,7 @@
 // Bounding box -> cell edge h with about one point per cell -> per-point cell id, histogram, exclusive scan, scatter
 // of (x, y, z, original index) records into cell order.  The sets are small next to the clouds (truth lists, cluster
 // centroids: 10^2..10^6 points), so the histogram and the scatter use plain global atomics.
+#include <algorithm>
 #include <cmath>
 
 #include "nngrid.hpp"
@@ -9,10 +10,14 @@
 namespace {
 constexpr int NT = 256;
 
-// out[0..2] = min, out[3..5] = max over finite values, out[6] = number of non-finite coordinates
-__global__ __launch_bounds__(NT) void k_nn_bounds(const double* __restrict__ p, int64_t n, double* __restrict__ out) {
+// out[0..2] = min, out[3..5] = max over finite values, out[6] = number of non-finite coordinates.  Up to NBB
+// workgroups; each leaves its seven partials in part[], the last one to finish (ticket in *done, which it leaves at
+// zero again) folds them.
+constexpr int NBB = 64;
+__global__ __launch_bounds__(NT) void k_nn_bounds(const double* __restrict__ p, int64_t n, double* __restrict__ part,
+                                                 uint32_t* __restrict__ done, double* __restrict__ out) {
   double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, bad = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += NT) {
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
 #pragma unroll
     for (int a = 0; a < 3; a++) {
       const double v = p[3 * i + a];
@@ -25,6 +30,7 @@ __global__ __launch_bounds__(NT) void k_nn_bounds(const double* __restrict__ p, 
     }
   }
   __shared__ double sm[NT / 64][7];
+  __shared__ bool last;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
   for (int a = 0; a < 3; a++) {
@@ -47,8 +53,23 @@ __global__ __launch_bounds__(NT) void k_nn_bounds(const double* __restrict__ p, 
     double v = sm[0][threadIdx.x];
     for (int k = 1; k < NT / 64; k++)
       v = threadIdx.x < 3 ? fmin(v, sm[k][threadIdx.x]) : threadIdx.x < 6 ? fmax(v, sm[k][threadIdx.x]) : v + sm[k][6];
+    __hip_atomic_store(&part[blockIdx.x * 8 + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(done, 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (threadIdx.x < 7) {
+    double v = __hip_atomic_load(&part[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t k = 1; k < gridDim.x; k++) {
+      const double o = __hip_atomic_load(&part[k * 8 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v = threadIdx.x < 3 ? fmin(v, o) : threadIdx.x < 6 ? fmax(v, o) : v + o;
+    }
     out[threadIdx.x] = v;
   }
+  if (threadIdx.x == 0) *done = 0;
 }
 
 __device__ __forceinline__ uint32_t cell_of(const NNGrid& g, const double* q) {
@@ -81,9 +102,13 @@ __global__ __launch_bounds__(NT) void k_nn_scatter(const double* __restrict__ p,
 int vcp_nngrid_build(vcp_ctx* ctx, const double* d_pts, int64_t n, NNGrid* out) {
   if (n <= 0 || n >= 0x7FFFFFF0LL / 3) return vcp_fail(ctx, VCP_ERR_ARG, "nngrid: bad size");
   hipStream_t st = ctx->stream;
-  VCP_TRY(vcp_ensure(ctx, ctx->b_nn_misc, 64 * sizeof(double)));
+  // b_nn_misc: [0..8) result, [8..16) the ticket word, [16 ..) NBB x 8 partials
+  const bool fresh = ctx->b_nn_misc.p == nullptr;
+  VCP_TRY(vcp_ensure(ctx, ctx->b_nn_misc, (size_t)(16 + NBB * 8) * sizeof(double)));
   double* d_b = ctx->b_nn_misc.as<double>();
-  hipLaunchKernelGGL(k_nn_bounds, dim3(1), dim3(NT), 0, st, d_pts, n, d_b);
+  if (fresh) VCP_HIP(ctx, hipMemsetAsync(d_b + 8, 0, 64, st));
+  const int nbb = (int)std::min<int64_t>(NBB, (n + 4 * NT - 1) / (4 * NT));
+  hipLaunchKernelGGL(k_nn_bounds, dim3(nbb), dim3(NT), 0, st, d_pts, n, d_b + 16, reinterpret_cast<uint32_t*>(d_b + 8), d_b);
   double* h = reinterpret_cast<double*>(ctx->pinned) + 64;
   VCP_HIP(ctx, hipMemcpyAsync(h, d_b, 7 * sizeof(double), hipMemcpyDeviceToHost, st));
   VCP_HIP(ctx, hipStreamSynchronize(st));

@@ -68,31 +68,54 @@ __device__ __forceinline__ void scan_range(const NNGrid& g, const double* p, uin
 }
 
 // order = index the sequential scan `min = f(0); for i: if (f(i) < min) ...` ends with; best = its value.
+// A query is worked by a GROUP of NNG lanes (consecutive lanes, all holding the same p): the rows of the searched block
+// are dealt round-robin to the lanes and the (value, index) pairs reduced with shuffles after every block, so a
+// query's chain of dependent loads (row bounds, then candidates) is an eighth as long -- the searches are latency
+// bound: 27 k queries are only 430 waves with one lane per query (27 k x 27 k matching: 297 -> see DESIGN.md).
+constexpr int NNG = 8;
+
 template <bool USE_SQRT>
-__device__ __forceinline__ void query(const NNGrid& g, const double* p, int& order, double& best) {
+__device__ __forceinline__ void query(const NNGrid& g, const double* p, int sub, int& order, double& best) {
   order = 0;
   best = INFINITY;  // (INFINITY, 0): what the C# keeps when no candidate compares smaller (non-finite query)
   const int cx = cell1(p[0], g.mn[0], g.inv_h, g.D[0]);
   const int cy = cell1(p[1], g.mn[1], g.inv_h, g.D[1]);
   const int cz = cell1(p[2], g.mn[2], g.inv_h, g.D[2]);
   const int maxd = max(g.D[0], max(g.D[1], g.D[2]));
+  auto reduce = [&]() {
+#pragma unroll
+    for (int d = 1; d < NNG; d <<= 1) {
+      const double ob = __shfl_xor(best, d, 64);
+      const int oo = __shfl_xor(order, d, 64);
+      if (ob < best || (ob == best && oo < order)) {
+        best = ob;
+        order = oo;
+      }
+    }
+  };
   for (int r = 1; r <= 8; r <<= 1) {
     const int x0 = max(cx - r, 0), x1 = min(cx + r, g.D[0] - 1);
     const int y0 = max(cy - r, 0), y1 = min(cy + r, g.D[1] - 1);
     const int z0 = max(cz - r, 0), z1 = min(cz + r, g.D[2] - 1);
+    int turn = 0;
     for (int z = z0; z <= z1; z++)
-      for (int y = y0; y <= y1; y++) {
+      for (int y = y0; y <= y1; y++, turn++) {
+        if ((turn & (NNG - 1)) != sub) continue;
         const uint32_t row = ((uint32_t)z * (uint32_t)g.D[1] + (uint32_t)y) * (uint32_t)g.D[0];
         scan_range<USE_SQRT>(g, p, g.cellstart[row + x0], g.cellstart[row + x1 + 1], best, order);
       }
+    reduce();
     // every point outside the block is at least r*h away (the margin covers the roundings of the cell arithmetic)
     const double lb = (double)r * g.h * (1.0 - 9.5367431640625e-07);
     const double lbv = USE_SQRT ? lb : lb * lb;
     if (best < lbv * (1.0 - 9.5367431640625e-07)) return;
     if (r >= maxd) return;  // the block covered the whole grid
   }
-  // far from everything: the whole set
-  scan_range<USE_SQRT>(g, p, 0u, (uint32_t)g.n, best, order);
+  // far from everything: the whole set, dealt in slices
+  const uint32_t n = (uint32_t)g.n, per = (n + NNG - 1) / NNG;
+  const uint32_t lo = min(n, per * (uint32_t)sub), hi = min(n, lo + per);
+  scan_range<USE_SQRT>(g, p, lo, hi, best, order);
+  reduce();
 }
 
 }  // namespace nng

@@ -227,6 +227,22 @@ int vcp_exclusive_max_scan_u32(vcp_ctx* ctx, const uint32_t* d_in, uint32_t* d_o
   return scan_u32<true>(ctx, d_in, d_out, n, d_total);
 }
 
+void* vcp_stage(vcp_ctx* ctx, size_t bytes) {
+  if (bytes > ((size_t)64 << 20)) return nullptr;
+  if (bytes <= ctx->stage_bytes) return ctx->stage;
+  if (ctx->stage) (void)hipHostFree(ctx->stage);
+  ctx->stage = nullptr;
+  ctx->stage_bytes = 0;
+  const size_t want = std::max(bytes + bytes / 2, (size_t)1 << 20);
+  if (hipHostMalloc(&ctx->stage, want, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->stage = nullptr;
+    return nullptr;
+  }
+  ctx->stage_bytes = want;
+  return ctx->stage;
+}
+
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
@@ -278,6 +294,9 @@ int vcp_release_workspace(vcp_ctx* ctx) {
     b->registered = false;
   }
   ctx->bufs.clear();  // vcp_ensure registers a buffer again when it allocates it
+  if (ctx->stage) (void)hipHostFree(ctx->stage);
+  ctx->stage = nullptr;
+  ctx->stage_bytes = 0;
   return VCP_OK;
 }
 
@@ -293,6 +312,7 @@ void vcp_destroy(vcp_ctx* ctx) {
   }
   for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->stage) (void)hipHostFree(ctx->stage);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }

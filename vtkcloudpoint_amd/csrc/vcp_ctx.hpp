@@ -33,6 +33,9 @@ struct vcp_ctx {
   // pinned scratch for tiny readbacks
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
+  // pinned staging area of the host-buffer entry points with several small arrays (vcp_stage; grown on demand, <= 64 MiB)
+  void* stage = nullptr;
+  size_t stage_bytes = 0;
   // workspace
   std::vector<DevBuf*> bufs;
   DevBuf b_cellcnt, b_cellof, b_rank, b_sorted, b_sidx, b_flags, b_parent, b_minord, b_seedflag,
@@ -49,6 +52,9 @@ struct vcp_ctx {
 };
 
 int vcp_fail(vcp_ctx* ctx, int code, const char* fmt, ...);
+// pinned host memory of at least `bytes` (nullptr when bytes > 64 MiB or the allocation fails: callers then copy
+// array by array from the caller's pageable memory)
+void* vcp_stage(vcp_ctx* ctx, size_t bytes);
 
 #define VCP_HIP(ctx, call)                                                                    \
   do {                                                                                        \

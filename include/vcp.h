@@ -69,6 +69,11 @@ int vcp_d2h(vcp_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
  * context; the next call allocates again. */
 int vcp_release_workspace(vcp_ctx* ctx);
 
+/* Self-test of the library's device prefix scan (every pipeline stage places its output with it): exclusive sum
+ * (op 0) or exclusive running maximum (op 1) of d_in [n] u32 into d_out [n] (d_out == d_in allowed), grand total to
+ * *total.  Device pointers; returns when the result is in place. */
+int vcp_selftest_scan_dev(vcp_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, int64_t n, int op, uint32_t* total);
+
 /* -- per-phase device timing (hipEvents on the launch stream) ----------------------------- */
 /* When enabled, every compute call records hipEvents around each kernel phase on the stream
  * it launches on.  vcp_timing_get returns the phases of the LAST call. */

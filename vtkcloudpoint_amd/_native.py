@@ -25,7 +25,7 @@ SYMBOLS = [
     "vcp_blocks_share", "vcp_blocks_cluster_dev", "vcp_blocks_finish_dev", "vcp_centroids", "vcp_centroids_dev",
     "vcp_merge_centroids", "vcp_refresh_by_dictionary", "vcp_icp", "vcp_icp_dev", "vcp_icp_sums",
     "vcp_match", "vcp_mcc", "vcp_assign_truths", "vcp_icp_vtklike", "vcp_import_convert",
-    "vcp_slab_begin", "vcp_slab_comps", "vcp_slab_finish", "vcp_release_workspace",
+    "vcp_slab_begin", "vcp_slab_comps", "vcp_slab_finish", "vcp_release_workspace", "vcp_selftest_scan_dev",
     "vcp_centroids_weighted", "vcp_dbscan_blocks_keyed", "vcp_blocks_begin_keyed", "vcp_blocks_begin_keyed_dev",
 ]
 
@@ -104,6 +104,12 @@ class Context:
     # -- plumbing ------------------------------------------------------------------------------
     def set_stream(self, stream_handle):
         self._chk(lib().vcp_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def selftest_scan_dev(self, in_ptr, out_ptr, n, op=0):
+        tot = C.c_uint32(0)
+        self._chk(lib().vcp_selftest_scan_dev(self._h, C.c_void_p(in_ptr), C.c_void_p(out_ptr), C.c_int64(n), C.c_int(op),
+                                              C.byref(tot)))
+        return tot.value
 
     def release_workspace(self):
         """Free the device workspace kept between calls (it is re-allocated on demand)."""

@@ -412,7 +412,7 @@ struct WorkList {
 // range were up to 34 % apart in entries on the C4 cloud).  The list is in position order, so a band of the
 // list is still one contiguous band of the cell-ordered arrays.  perblk = workgroups per band.
 __device__ __forceinline__ uint32_t wl_fetch(const WorkList& w) {
-  const uint32_t total = w.scan[w.nblk];
+  const uint32_t total = w.scan[w.nblk] - w.scan[0];  // the scan may start at an offset (both lists share one)
   const uint32_t x = blockIdx.x & 7u, i = blockIdx.x >> 3;
   const uint32_t c = (i / w.perblk) * 8u + x;  // band
   const uint32_t lo = (uint32_t)(((uint64_t)total * c) / (8u * LCHUNK));
@@ -447,7 +447,18 @@ __device__ __forceinline__ void wl_count(bool isE, bool isB, uint32_t blk, uint3
 __global__ __launch_bounds__(TPB) void k_wl_fill(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ cellstart,
                                                 uint32_t ncells, const uint32_t* __restrict__ scanE,
                                                 const uint32_t* __restrict__ scanB, uint32_t* __restrict__ listE,
-                                                uint32_t* __restrict__ listB) {
+                                                uint32_t* __restrict__ listB, uint32_t* __restrict__ seedflag, uint32_t nw,
+                                                unsigned long long* __restrict__ counters) {
+  // also: clears the seed bitmap (8 words per workgroup of 256 positions, the tail by workgroup 0) and the counters
+  // for the phases that follow
+  if (threadIdx.x < 8) {
+    const uint32_t wd = blockIdx.x * 8u + threadIdx.x;
+    if (wd < nw) seedflag[wd] = 0u;
+  }
+  if (blockIdx.x == 0) {
+    for (uint32_t wd = gridDim.x * 8u + threadIdx.x; wd < nw; wd += TPB) seedflag[wd] = 0u;
+    if (threadIdx.x < 68) counters[threadIdx.x] = 0ull;
+  }
   const uint32_t nin = cellstart[ncells];
   const int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
   const uint8_t fl = p < nin ? flags[p] : 0;
@@ -460,7 +471,7 @@ __global__ __launch_bounds__(TPB) void k_wl_fill(const uint8_t* __restrict__ fla
     wo[1][w] = (unsigned)__popcll(mB);
   }
   __syncthreads();
-  unsigned oE = scanE[blockIdx.x], oB = scanB[blockIdx.x];
+  unsigned oE = scanE[blockIdx.x] - scanE[0], oB = scanB[blockIdx.x] - scanB[0];
   for (int k = 0; k < w; k++) {
     oE += wo[0][k];
     oB += wo[1][k];
@@ -522,7 +533,7 @@ __global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted,
                                              const int32_t* __restrict__ sgroup, uint8_t* __restrict__ flags,
                                              uint32_t* __restrict__ parent, uint32_t* __restrict__ minord,
                                              uint32_t* __restrict__ blkE, uint32_t* __restrict__ blkB, NbrOut no,
-                                             const float* __restrict__ sorted32, Screen sc) {
+                                             const float* __restrict__ sorted32, Screen sc, bool has_cls) {
   extern __shared__ uint32_t lnb[];  // [NB * TPB] staged lists, then [NB * TPB] for their compaction
   const uint32_t nin = cellstart[g.ncells];
   const int64_t blk = xcd_block(gridDim.x);
@@ -563,7 +574,7 @@ __global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted,
     }
     return true;
   });
-  uint8_t fl = live ? flags[p] : 0;
+  uint8_t fl = live && has_cls ? flags[p] : 0;  // has_cls: the build stored F_CLASSED bits (else nothing is there yet)
   bool isE = false, isB = false;
   if (!live) {
   } else if (cnt >= min_pts) {
@@ -720,7 +731,7 @@ __global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sor
                                                  const uint32_t* __restrict__ cellstart, uint8_t* __restrict__ flags,
                                                  uint32_t* __restrict__ parent, uint32_t* __restrict__ minord,
                                                  uint32_t* __restrict__ blkE, uint32_t* __restrict__ blkB, NbrOut no,
-                                                 const float* __restrict__ sorted32, Screen sc) {
+                                                 const float* __restrict__ sorted32, Screen sc, bool has_cls) {
   constexpr int NR = CoreTile<GD>::NR;
   constexpr int OWN = NR / 2;  // the row of the point's own cell (dy = dz = 0)
   __shared__ CoreTile<GD> t;
@@ -823,7 +834,7 @@ __global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sor
     }
     nrec = min(nrec, no.NB);
   }
-  uint8_t fl = live ? flags[p] : 0;
+  uint8_t fl = live && has_cls ? flags[p] : 0;  // has_cls: the build stored F_CLASSED bits (else nothing is there yet)
   bool isE = false, isB = false;
   if (!live) {
   } else if (cnt >= min_pts) {
@@ -1776,10 +1787,13 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   // 4. cell order.  Two-level partition that carries the coordinates (gridbuild.hip); grids too large for its
   //    one-level coarse split keep the round-1 build: sort (cell id, index) pairs, cell starts from the sorted keys,
   //    gather.  The partition's output pass needs no caller-order -> cell-order map (pos).
+  // flags before the core count: the build stores the callers' isClassed bits; without them the core count starts every
+  // byte itself and nothing has to be there
+  const bool flags_set = d_in_classed != nullptr;
   const bool part = vcp_grid_partition_fits(n, g.ncells);
   const bool part_out = part && !GROUPED && !d_ord && !(ext && ext->slab) && n <= ((int64_t)1 << 27);
   if (part) {
-    if (!d_in_classed) VCP_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)n, st));
+    if (!flags_set && GROUPED) VCP_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)n, st));  // bytes of excluded points
     GridBuildArgs ga;
     ga.d_coords = d_coords;
     ga.n = n;
@@ -1823,7 +1837,7 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
     VCP_TRY(vcp_exclusive_max_scan_u32(ctx, tilestart, tilestart, ntiles + 1, nullptr));
     hipLaunchKernelGGL(k_cellstart_tiles, dim3((unsigned)ntiles), dim3(TPB), 0, st, skey, tilestart, g.ncells, cellcnt);
     vcp_phase(ctx, "scatter");
-    if (!d_in_classed) VCP_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)n, st));
+    if (!flags_set && GROUPED) VCP_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)n, st));  // bytes of excluded points
     hipLaunchKernelGGL((k_gather<GD, GROUPED>), dim3(nb), dim3(TPB), 0, st, d_coords, stride, cellcnt, g.ncells, sidx,
                        d_in_classed, d_group, d_ord, pos, sorted, sord, sgroup, flags, sorted32, g);
   }
@@ -1840,7 +1854,6 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   wlB.scan = blkB;
   wlE.nblk = wlB.nblk = nb;
   wlE.perblk = wlB.perblk = list_perblk(n);
-  VCP_HIP(ctx, hipMemsetAsync(blkE, 0, (size_t)(nb + 2) * 2 * 4, st));
   const unsigned nbl = 8u * LCHUNK * wlE.perblk;  // list kernels: see wl_fetch
   // neighbour lists (see NbrOut): off when the caller passes isClassed (classed core points need the full search), for
   // staged calls (vcp_slab_finish searches again with the resolved ids) and for min_pts outside 2..16
@@ -1856,18 +1869,18 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   const size_t lds_nb = (size_t)no.NB * TPB * 4;
   if constexpr (GD == 2 && !GROUPED)
     hipLaunchKernelGGL((k_core_lds<GD, METRIC>), dim3(nb), dim3(TPB), 0, st, sorted, g, thr, min_pts, cellcnt, flags, parent,
-                       minord, blkE, blkB, no, sorted32, sc);
+                       minord, blkE, blkB, no, sorted32, sc, flags_set);
   else
     hipLaunchKernelGGL((k_core<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 2 * lds_nb, st, sorted, g, thr, min_pts, cellcnt,
-                       sgroup, flags, parent, minord, blkE, blkB, no, sorted32, sc);
-  VCP_TRY(vcp_exclusive_scan_u32(ctx, blkE, blkE, (int64_t)nb + 1, nullptr));
-  VCP_TRY(vcp_exclusive_scan_u32(ctx, blkB, blkB, (int64_t)nb + 1, nullptr));
-  hipLaunchKernelGGL(k_wl_fill, dim3(nb), dim3(TPB), 0, st, flags, cellcnt, g.ncells, blkE, blkB, wlE.list, wlB.list);
+                       sgroup, flags, parent, minord, blkE, blkB, no, sorted32, sc, flags_set);
+  // ONE scan over both count arrays (they are adjacent): the B half comes out offset by everything before it, which
+  // its readers take off again (scan[0]); the two pad words between the halves are never written and cancel the same way
+  VCP_TRY(vcp_exclusive_scan_u32(ctx, blkE, blkE, 2 * ((int64_t)nb + 2), nullptr));
+  hipLaunchKernelGGL(k_wl_fill, dim3(nb), dim3(TPB), 0, st, flags, cellcnt, g.ncells, blkE, blkB, wlE.list, wlB.list,
+                     seedflag, nw, counters);
 
   // 6. components of the expanding points
   vcp_phase(ctx, "union");
-  VCP_HIP(ctx, hipMemsetAsync(seedflag, 0, (size_t)nw * 4, st));
-  VCP_HIP(ctx, hipMemsetAsync(counters, 0, 68 * sizeof(unsigned long long), st));
   // phases 1-2 pay for their extra search pass in 2-D (3 rows); in 3-D (9 rows) they do not (measured: +28 %)
   const bool pre = GD == 2 || no.NB > 0;  // with lists the forest costs no search, so it pays in 3-D too
   if (no.NB > 0) {

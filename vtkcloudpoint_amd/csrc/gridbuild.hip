@@ -314,8 +314,9 @@ __global__ __launch_bounds__(OT) void k_out_scatter(const uint32_t* __restrict__
 __global__ __launch_bounds__(OWT) void k_out_write(const uint2* __restrict__ rec, int64_t n, bool have_in_classed,
                                                   int32_t cf_in, int32_t* __restrict__ labels,
                                                   uint8_t* __restrict__ is_core, uint8_t* __restrict__ is_classed,
-                                                  unsigned long long* __restrict__ counters) {
+                                                  unsigned long long* __restrict__ counters, uint32_t* __restrict__ gcur) {
   __shared__ int32_t sl[1 << OWSH];
+  if (threadIdx.x == 0) gcur[blockIdx.x] = 0u;  // the window cursors are left at zero for the next call
   __shared__ __attribute__((aligned(16))) uint8_t sc[1 << OWSH], sk[1 << OWSH];
   const int64_t lo = (int64_t)blockIdx.x << OWSH;
   const uint32_t cnt = (uint32_t)min((int64_t)1 << OWSH, n - lo);  // every list position appears exactly once
@@ -427,17 +428,21 @@ int vcp_grid_output_partition(vcp_ctx* ctx, const GridOutputArgs& a) {
   hipStream_t st = ctx->stream;
   const uint32_t OB = (uint32_t)((a.n + (1 << OWSH) - 1) >> OWSH);
   if (OB > 16384) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "more than 2^27 points: use the gather output");
-  VCP_TRY(vcp_ensure(ctx, ctx->b_hist, ((size_t)OB + 8) * 4));
+  // window cursors: zero between calls (k_out_write leaves them so), cleared here only when the array is new
+  const void* before = ctx->b_outcur.p;
+  const size_t before_cap = ctx->b_outcur.cap;
+  VCP_TRY(vcp_ensure(ctx, ctx->b_outcur, ((size_t)OB + 8) * 4));
+  if (ctx->b_outcur.p != before || ctx->b_outcur.cap != before_cap)
+    VCP_HIP(ctx, hipMemsetAsync(ctx->b_outcur.p, 0, ctx->b_outcur.cap, st));
   VCP_TRY(vcp_ensure(ctx, ctx->b_rec, (size_t)OB << (OWSH + 3)));
-  uint32_t* gcur = ctx->b_hist.as<uint32_t>();
+  uint32_t* gcur = ctx->b_outcur.as<uint32_t>();
   uint2* rec = ctx->b_rec.as<uint2>();
   vcp_phase(ctx, "out_scatter");
-  VCP_HIP(ctx, hipMemsetAsync(gcur, 0, (size_t)OB * 4, st));
   hipLaunchKernelGGL(k_out_scatter, dim3(vcp_blocks(a.n, OT * OPT)), dim3(OT), (size_t)OB * 4, st, a.sord, a.labk, a.n, OB,
                      gcur, rec);
   vcp_phase(ctx, "out_write");
   hipLaunchKernelGGL(k_out_write, dim3(OB), dim3(OWT), 0, st, rec, a.n, a.have_in_classed, a.cf_in, a.labels, a.is_core,
-                     a.is_classed, a.counters);
+                     a.is_classed, a.counters, gcur);
   VCP_HIP(ctx, hipGetLastError());
   return VCP_OK;
 }

@@ -76,11 +76,18 @@ int vcp_phase_finish(vcp_ctx* ctx) {
 }
 
 // ------------------------------------------------------------------------------------------
-// exclusive scan (u32), reduce-then-scan over tiles of 8192 elements:
-//   k_scan_tile_sums  one workgroup per tile, 16-B loads, tile sum
-//   k_scan_offsets    one workgroup scans the tile sums (and emits the grand total)
-//   k_scan_tiles      one workgroup per tile re-reads it, scans it in 8 chunks of 1024 with a running carry
-// 2 reads + 1 write of the array; in-place allowed (a tile is read before it is written, tiles are disjoint).
+// exclusive scan (u32), ONE kernel: tiles of 8192 elements chained by decoupled look-back.
+//   * a workgroup takes its tile number from a ticket counter (tiles therefore start in order: whatever a tile waits
+//     for belongs to a workgroup that is already running), loads its 8 x 1024 elements into registers (16-B loads),
+//     reduces them and publishes the tile aggregate;
+//   * wave 0 walks back over the descriptors of the preceding tiles, 64 at a time, adding aggregates until it meets
+//     a tile whose inclusive prefix is known, publishes its own inclusive prefix, and the tile is scanned out of the
+//     registers: 1 read + 1 write of the array (the three-kernel reduce-then-scan it replaces read it twice and cost
+//     16 us + two launch gaps per call; the DBSCAN step makes four such calls).
+// A descriptor is one 64-bit word {generation << 2 | state, value}, written and read with single relaxed atomics: no
+// fences, and no clearing between calls -- the generation number (per context, one per call) tells a fresh word from a
+// stale one.  The descriptor array is zero-filled when it is (re)allocated; the last ticket holder resets the ticket.
+// In-place allowed (a tile is in registers before it is written; tiles are disjoint).
 // ------------------------------------------------------------------------------------------
 namespace {
 constexpr int ST = 256;            // threads
@@ -103,28 +110,6 @@ __device__ __forceinline__ uint32_t wave_incl(uint32_t v, int lane) {
   return v;
 }
 
-// block-wide exclusive scan of one value per thread; *total = block sum (max).  Two barriers.
-template <bool MX>
-__device__ __forceinline__ uint32_t block_excl(uint32_t v, uint32_t* total, uint32_t* sm /*[ST/64 + 1]*/) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const uint32_t inc = wave_incl<MX>(v, lane);
-  if (lane == 63) sm[w] = inc;
-  __syncthreads();
-  uint32_t base = 0, tot = 0;
-#pragma unroll
-  for (int k = 0; k < ST / 64; k++) {
-    const uint32_t x = sm[k];
-    if (k < w) base = sop<MX>(base, x);
-    tot = sop<MX>(tot, x);
-  }
-  __syncthreads();
-  *total = tot;
-  // exclusive value of this thread: everything before it in its wave, plus the earlier waves
-  uint32_t prev = __shfl_up(inc, 1, 64);
-  if (lane == 0) prev = 0;
-  return sop<MX>(base, prev);
-}
-
 template <bool VEC>
 __device__ __forceinline__ uint4 ld4(const uint32_t* __restrict__ in, int64_t i, int64_t n) {
   if (VEC && i + 3 < n) return *reinterpret_cast<const uint4*>(in + i);
@@ -136,84 +121,133 @@ __device__ __forceinline__ uint4 ld4(const uint32_t* __restrict__ in, int64_t i,
   return v;
 }
 
+constexpr uint32_t SD_AGG = 1u, SD_INC = 2u;  // descriptor states: tile aggregate / inclusive prefix available
+
+__device__ __forceinline__ void sd_put(unsigned long long* d, uint32_t gen, uint32_t state, uint32_t v) {
+  __hip_atomic_store(d, ((unsigned long long)((gen << 2) | state) << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <bool VEC, bool MX>
-__global__ __launch_bounds__(ST) void k_scan_tile_sums(const uint32_t* __restrict__ in, int64_t n,
-                                                      uint32_t* __restrict__ tsum) {
-  const int64_t base = (int64_t)blockIdx.x * STILE;
-  uint32_t s = 0;
+__global__ __launch_bounds__(ST) void k_scan(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int64_t n,
+                                            uint32_t nt, uint32_t gen, uint32_t* __restrict__ ticket,
+                                            unsigned long long* __restrict__ desc, uint32_t* __restrict__ total) {
+  __shared__ uint32_t s_tile, s_carry;
+  __shared__ uint32_t sm[SCH][ST / 64];
+  if (threadIdx.x == 0) {
+    const uint32_t t = atomicAdd(ticket, 1u);
+    if (t == nt - 1) atomicExch(ticket, 0u);  // every ticket of this call has been handed out
+    s_tile = t;
+    s_carry = 0u;
+  }
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const int64_t base = (int64_t)tile * STILE;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint4 v[SCH];
+  uint32_t inc[SCH];
+#pragma unroll
+  for (int k = 0; k < SCH; k++) v[k] = ld4<VEC>(in, base + ((int64_t)k * ST + threadIdx.x) * 4, n);
 #pragma unroll
   for (int k = 0; k < SCH; k++) {
-    const uint4 v = ld4<VEC>(in, base + ((int64_t)k * ST + threadIdx.x) * 4, n);
-    s = sop<MX>(s, sop<MX>(sop<MX>(v.x, v.y), sop<MX>(v.z, v.w)));
+    inc[k] = wave_incl<MX>(sop<MX>(sop<MX>(v[k].x, v[k].y), sop<MX>(v[k].z, v[k].w)), lane);
+    if (lane == 63) sm[k][w] = inc[k];
   }
-  __shared__ uint32_t sm[ST / 64 + 1];
-  uint32_t tot;
-  block_excl<MX>(s, &tot, sm);
-  if (threadIdx.x == 0) tsum[blockIdx.x] = tot;
-}
-
-// single workgroup: exclusive scan of nt tile sums in place; thread t owns a contiguous run
-template <bool MX>
-__global__ __launch_bounds__(ST) void k_scan_offsets(uint32_t* __restrict__ tsum, int nt, uint32_t* __restrict__ total) {
-  const int per = (nt + ST - 1) / ST;
-  const int lo = min((int)threadIdx.x * per, nt), hi = min(lo + per, nt);
-  uint32_t s = 0;
-  for (int i = lo; i < hi; i++) s = sop<MX>(s, tsum[i]);
-  __shared__ uint32_t sm[ST / 64 + 1];
-  uint32_t tot;
-  uint32_t pre = block_excl<MX>(s, &tot, sm);
-  for (int i = lo; i < hi; i++) {
-    const uint32_t v = tsum[i];
-    tsum[i] = pre;
-    pre = sop<MX>(pre, v);
+  __syncthreads();
+  // element order is chunk-major: everything in earlier chunks, then the earlier waves of the own chunk
+  uint32_t agg = 0, pre[SCH];
+#pragma unroll
+  for (int k = 0; k < SCH; k++) {
+    uint32_t b = agg;
+#pragma unroll
+    for (int ww = 0; ww < ST / 64; ww++) {
+      const uint32_t x = sm[k][ww];
+      if (ww < w) b = sop<MX>(b, x);
+      agg = sop<MX>(agg, x);
+    }
+    pre[k] = b;
   }
-  if (threadIdx.x == 0 && total) *total = tot;
-}
-
-template <bool VEC, bool MX>
-__global__ __launch_bounds__(ST) void k_scan_tiles(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int64_t n,
-                                                  const uint32_t* __restrict__ toff) {
-  const int64_t base = (int64_t)blockIdx.x * STILE;
-  __shared__ uint32_t sm[ST / 64 + 1];
-  uint32_t carry = toff[blockIdx.x];
-#pragma unroll 1
+  if (w == 0) {
+    if (tile == 0) {
+      if (lane == 0) sd_put(&desc[0], gen, SD_INC, agg);
+    } else {
+      if (lane == 0) sd_put(&desc[tile], gen, SD_AGG, agg);
+      uint32_t carry = 0;
+      int64_t j0 = (int64_t)tile - 1;  // lane l looks at tile j0 - l
+      for (;;) {
+        const int64_t j = j0 - lane;
+        uint32_t stt = SD_INC, val = 0;  // before tile 0: an inclusive prefix of nothing
+        if (j >= 0) {
+          unsigned long long d;
+          do {
+            d = __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } while ((uint32_t)(d >> 34) != gen || ((uint32_t)(d >> 32) & 3u) == 0u);
+          stt = (uint32_t)(d >> 32) & 3u;
+          val = (uint32_t)d;
+        }
+        const unsigned long long incm = __ballot(stt == SD_INC);
+        const int first = __ffsll((long long)incm) - 1;  // nearest tile with a known prefix; -1: 64 aggregates, go on
+        uint32_t x = (first < 0 || lane <= first) ? val : 0u;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) x = sop<MX>(x, (uint32_t)__shfl_xor((int)x, d, 64));
+        carry = sop<MX>(carry, x);
+        if (first >= 0) break;
+        j0 -= 64;
+      }
+      if (lane == 0) {
+        sd_put(&desc[tile], gen, SD_INC, sop<MX>(carry, agg));
+        s_carry = carry;
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t carry = s_carry;
+  if (total && tile == nt - 1 && threadIdx.x == 0) *total = sop<MX>(carry, agg);
+#pragma unroll
   for (int k = 0; k < SCH; k++) {
     const int64_t i = base + ((int64_t)k * ST + threadIdx.x) * 4;
-    const uint4 v = ld4<VEC>(in, i, n);
-    uint32_t tot;
-    const uint32_t pre =
-        sop<MX>(carry, block_excl<MX>(sop<MX>(sop<MX>(v.x, v.y), sop<MX>(v.z, v.w)), &tot, sm));
-    const uint32_t o1 = sop<MX>(pre, v.x), o2 = sop<MX>(o1, v.y), o3 = sop<MX>(o2, v.z);
-    const uint4 o = make_uint4(pre, o1, o2, o3);
+    uint32_t prev = __shfl_up(inc[k], 1, 64);
+    if (lane == 0) prev = 0;
+    const uint32_t p0 = sop<MX>(sop<MX>(carry, pre[k]), prev);
+    const uint32_t o1 = sop<MX>(p0, v[k].x), o2 = sop<MX>(o1, v[k].y), o3 = sop<MX>(o2, v[k].z);
     if (VEC && i + 3 < n) {
-      *reinterpret_cast<uint4*>(out + i) = o;
+      *reinterpret_cast<uint4*>(out + i) = make_uint4(p0, o1, o2, o3);
     } else {
-      if (i < n) out[i] = o.x;
-      if (i + 1 < n) out[i + 1] = o.y;
-      if (i + 2 < n) out[i + 2] = o.z;
-      if (i + 3 < n) out[i + 3] = o.w;
+      if (i < n) out[i] = p0;
+      if (i + 1 < n) out[i + 1] = o1;
+      if (i + 2 < n) out[i + 2] = o2;
+      if (i + 3 < n) out[i + 3] = o3;
     }
-    carry = sop<MX>(carry, tot);
   }
 }
 }  // namespace
 
 template <bool MX>
 static int scan_u32(vcp_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, int64_t n, uint32_t* d_total) {
+  hipStream_t st = ctx->stream;
   if (n <= 0) {
-    if (d_total) VCP_HIP(ctx, hipMemsetAsync(d_total, 0, 4, ctx->stream));
+    if (d_total) VCP_HIP(ctx, hipMemsetAsync(d_total, 0, 4, st));
     return VCP_OK;
   }
   const int64_t nt = (n + STILE - 1) / STILE;
-  VCP_TRY(vcp_ensure(ctx, ctx->b_scan_tmp, (size_t)(nt + 16) * sizeof(uint32_t)));
-  uint32_t* tsum = ctx->b_scan_tmp.as<uint32_t>();
+  if (nt >= ((int64_t)1 << 31)) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "scan of %lld elements", (long long)n);
+  // [0, 64) bytes: the ticket; then one descriptor per tile
+  const void* before = ctx->b_scan_tmp.p;
+  const size_t before_cap = ctx->b_scan_tmp.cap;
+  VCP_TRY(vcp_ensure(ctx, ctx->b_scan_tmp, 64 + (size_t)nt * 8));
+  ctx->scan_gen = (ctx->scan_gen + 1u) & 0x3FFFFFFFu;
+  if (ctx->b_scan_tmp.p != before || ctx->b_scan_tmp.cap != before_cap || ctx->scan_gen == 0u) {  // fresh memory, or the generation numbers wrapped round
+    VCP_HIP(ctx, hipMemsetAsync(ctx->b_scan_tmp.p, 0, ctx->b_scan_tmp.cap, st));
+    if (ctx->scan_gen == 0u) ctx->scan_gen = 1u;
+  }
+  uint32_t* ticket = ctx->b_scan_tmp.as<uint32_t>();
+  unsigned long long* desc = reinterpret_cast<unsigned long long*>(ctx->b_scan_tmp.as<char>() + 64);
   const bool vec = (((uintptr_t)d_in | (uintptr_t)d_out) & 15u) == 0;
-  hipStream_t st = ctx->stream;
-  if (vec) hipLaunchKernelGGL((k_scan_tile_sums<true, MX>), dim3((unsigned)nt), dim3(ST), 0, st, d_in, n, tsum);
-  else hipLaunchKernelGGL((k_scan_tile_sums<false, MX>), dim3((unsigned)nt), dim3(ST), 0, st, d_in, n, tsum);
-  hipLaunchKernelGGL(k_scan_offsets<MX>, dim3(1), dim3(ST), 0, st, tsum, (int)nt, d_total);
-  if (vec) hipLaunchKernelGGL((k_scan_tiles<true, MX>), dim3((unsigned)nt), dim3(ST), 0, st, d_in, d_out, n, tsum);
-  else hipLaunchKernelGGL((k_scan_tiles<false, MX>), dim3((unsigned)nt), dim3(ST), 0, st, d_in, d_out, n, tsum);
+  if (vec)
+    hipLaunchKernelGGL((k_scan<true, MX>), dim3((unsigned)nt), dim3(ST), 0, st, d_in, d_out, n, (uint32_t)nt, ctx->scan_gen,
+                       ticket, desc, d_total);
+  else
+    hipLaunchKernelGGL((k_scan<false, MX>), dim3((unsigned)nt), dim3(ST), 0, st, d_in, d_out, n, (uint32_t)nt, ctx->scan_gen,
+                       ticket, desc, d_total);
   VCP_HIP(ctx, hipGetLastError());
   return VCP_OK;
 }
@@ -280,6 +314,20 @@ int vcp_create(int device_id, vcp_ctx** out) {
 
 void vcp_blocks_state_free(vcp_ctx* ctx);  // blocks.hip
 void vcp_slab_state_free(vcp_ctx* ctx);    // dbscan.hip
+
+int vcp_selftest_scan_dev(vcp_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, int64_t n, int op, uint32_t* total) {
+  if (!ctx) return VCP_ERR_ARG;
+  if (n < 0 || (n > 0 && (!d_in || !d_out)) || (op != 0 && op != 1)) return vcp_fail(ctx, VCP_ERR_ARG, "bad argument");
+  VCP_TRY(vcp_bind(ctx));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_self, 64));
+  uint32_t* d_tot = ctx->b_self.as<uint32_t>();
+  VCP_TRY(op ? vcp_exclusive_max_scan_u32(ctx, d_in, d_out, n, d_tot) : vcp_exclusive_scan_u32(ctx, d_in, d_out, n, d_tot));
+  uint32_t* h = reinterpret_cast<uint32_t*>(ctx->pinned);
+  VCP_HIP(ctx, hipMemcpyAsync(h, d_tot, 4, hipMemcpyDeviceToHost, ctx->stream));
+  VCP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (total) *total = h[0];
+  return VCP_OK;
+}
 
 int vcp_release_workspace(vcp_ctx* ctx) {
   if (!ctx) return VCP_ERR_ARG;

@@ -206,3 +206,27 @@ def test_release_workspace_and_reuse(oracle):
     with pytest.raises(N.VcpError):  # the staged block state went with the workspace
         ctx.blocks_share(0, 1)
     ctx.close()
+
+
+@pytest.mark.parametrize("metric,dim", [(N.L1_2D, 2), (N.L1_2D, 3), (N.L2_2D, 2), (N.L2_3D, 3)])
+def test_lattice_every_neighbour_exactly_on_eps(vcp_ctx, oracle, metric, dim):
+    """Points of an integer lattice (with holes and duplicates), eps = the lattice step: every neighbour pair sits
+    exactly on the threshold, so the binary32 screen decides nothing and every pair goes through the exact binary64
+    re-test -- which reads the coordinates from the caller's array by index (2-D cloud passed with stride 3 too).
+    Also off the origin, where the binary32 relative coordinates round."""
+    rng = np.random.default_rng(900 + 10 * metric + dim)
+    side = 150 if dim == 2 or metric != N.L2_3D else 30
+    nd = 3 if metric == N.L2_3D else 2
+    pts = rng.integers(0, side, size=(60_000, nd)).astype(np.float64)
+    c = np.zeros((len(pts), dim))
+    c[:, :nd] = pts
+    if dim == 3 and nd == 2:
+        c[:, 2] = rng.random(len(c)) * 1e6  # ignored by the 2-D metrics
+    for shift, step in ((0.0, 1.0), (123456.75, 0.5)):
+        cc = c.copy()
+        cc[:, :nd] = cc[:, :nd] * step + shift
+        for mp in (3, 6, 20):
+            o = oracle.dbscan(cc, step, mp, metric)
+            g = vcp_ctx.dbscan(cc, step, mp, metric)
+            _same(g, o, "shift %g mp %d" % (shift, mp))
+            assert np.array_equal(g["is_core"], o["is_key"])

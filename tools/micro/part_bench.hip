@@ -34,7 +34,7 @@ __global__ void k_hist(const uint32_t* __restrict__ key, size_t n, uint32_t B, u
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < B; k += PT) counts[(size_t)k * nchunk + blockIdx.x] = h[k];
 }
-template <int MODE>  // 0 SoA 16+4, 1 AoS 32 B
+template <int MODE>  // 0 SoA 16+4, 1 AoS 32 B, 2 AoS 16 B
 __global__ __launch_bounds__(PT) void k_scatter(const double2* __restrict__ xy, const uint32_t* __restrict__ key, size_t n, uint32_t B,
                                                uint32_t chunk, uint32_t nchunk, const uint32_t* __restrict__ base, double2* oxy,
                                                uint32_t* oidx, double4* oaos) {
@@ -49,8 +49,11 @@ __global__ __launch_bounds__(PT) void k_scatter(const double2* __restrict__ xy, 
     if (MODE == 0) {
       oxy[dst] = v;
       oidx[dst] = (uint32_t)i;
-    } else {
+    } else if (MODE == 1) {
       oaos[dst] = make_double4(v.x, v.y, __hiloint2double(0, (int)i), 0.0);
+    } else {  // 16-byte record: binary32 coordinates, index, key
+      reinterpret_cast<float4*>(oaos)[dst] =
+          make_float4((float)v.x, (float)v.y, __uint_as_float((uint32_t)i), __uint_as_float(key[i]));
     }
   }
 }
@@ -203,7 +206,7 @@ int main() {
   timeit("copy 16+4 B", [&] { hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, 0, xy, perm, oxy, oidx, n); });
   timeit("gather 16 B by random index", [&] { hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), dim3(256), 0, 0, xy, perm, oxy, n); });
   std::vector<uint32_t> hkey(n), hc;
-  for (uint32_t B : {64u, 256u, 1024u, 4096u}) {
+  for (uint32_t B : {1024u, 4096u, 8192u}) {
     for (size_t i = 0; i < n; i++) hkey[i] = rng() % B;
     CK(hipMemcpy(key, hkey.data(), n * 4, hipMemcpyHostToDevice));
     for (uint32_t chunk : {10240u, 40960u}) {
@@ -221,6 +224,8 @@ int main() {
       timeit(nm, [&] { hipLaunchKernelGGL(k_scatter<0>, dim3(nchunk), dim3(PT), B * 4, 0, xy, key, n, B, chunk, nchunk, counts, oxy, oidx, oaos); });
       snprintf(nm, sizeof nm, "aos32  B=%u chunk=%u", B, chunk);
       timeit(nm, [&] { hipLaunchKernelGGL(k_scatter<1>, dim3(nchunk), dim3(PT), B * 4, 0, xy, key, n, B, chunk, nchunk, counts, oxy, oidx, oaos); });
+      snprintf(nm, sizeof nm, "aos16  B=%u chunk=%u", B, chunk);
+      timeit(nm, [&] { hipLaunchKernelGGL(k_scatter<2>, dim3(nchunk), dim3(PT), B * 4, 0, xy, key, n, B, chunk, nchunk, counts, oxy, oidx, oaos); });
       const size_t lds = (size_t)B * 8 + (size_t)SUB * 12 + (size_t)SUB * 16 + 64;
       if (lds > 64 * 1024) {
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter_staged<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -60,6 +60,7 @@ struct SlabState {
   int64_t n = 0, n_comp = 0;
   GridP g;
   double thr = 0.0;
+  Screen sc{-1.0f, INFINITY};
   unsigned nb = 0;
 };
 
@@ -96,13 +97,14 @@ __device__ __forceinline__ float value32(const float* a, const float* b) {
 // the predicate through the screen: binary32 where it is provably the binary64 answer, else the exact expression on
 // the binary64 coordinates of the two cell-ordered positions
 template <int GD, int METRIC>
-__device__ __forceinline__ bool within_scr(const float* qf, const float* cf, Screen sc, const double* q,
-                                           const double* __restrict__ sorted, uint32_t j, double thr) {
+__device__ __forceinline__ bool within_scr(const float* qf, const float* cf, Screen sc, const ExactSrc& xs, uint32_t p,
+                                           uint32_t j, double thr) {
   const float v = value32<METRIC>(qf, cf);
   if (v <= sc.lo) return true;
   if (v > sc.hi) return false;
-  double r[3];
-  load_pt<GD>(sorted, j, r);
+  double q[3], r[3];
+  load_exact<GD>(xs, p, q);
+  load_exact<GD>(xs, j, r);
   return within<METRIC>(q, r, thr);
 }
 
@@ -308,6 +310,19 @@ __global__ __launch_bounds__(TPB) void k_cellstart_tiles(const uint32_t* __restr
   // coalesced store; cells up to and including index ncells (= number of included points) exist in the table
   for (int k = threadIdx.x; k < CTILE; k += TPB)
     if (c0 + (uint32_t)k <= ncells) cellstart[c0 + k] = cnt[at(k)];
+}
+
+// cell-ordered binary64 copy after a partition build, for the staged calls (vcp_slab_*): their second stage runs in a
+// later call, when the caller's array need no longer be there
+template <int GD>
+__global__ __launch_bounds__(TPB) void k_exact_copy(ExactSrc xs, const uint32_t* __restrict__ cellstart, uint32_t ncells,
+                                                   double* __restrict__ sorted) {
+  const uint32_t nin = cellstart[ncells];
+  const int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (p >= nin) return;
+  double q[3];
+  load_exact<GD>(xs, (uint32_t)p, q);
+  store_pt<GD>(sorted, p, q);
 }
 
 template <int GD, bool GROUPED>
@@ -528,7 +543,7 @@ __device__ __forceinline__ void nbr_flush(const NbrOut& no, const uint32_t* lnb,
 }
 
 template <int GD, int METRIC, bool GROUPED>
-__global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted, GridP g, double thr, int min_pts,
+__global__ __launch_bounds__(TPB) void k_core(ExactSrc xs, GridP g, double thr, int min_pts,
                                              const uint32_t* __restrict__ cellstart,
                                              const int32_t* __restrict__ sgroup, uint8_t* __restrict__ flags,
                                              uint32_t* __restrict__ parent, uint32_t* __restrict__ minord,
@@ -539,18 +554,16 @@ __global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted,
   const int64_t blk = xcd_block(gridDim.x);
   int64_t p = blk * TPB + threadIdx.x;
   const bool live = p < nin;
-  double q[3] = {0, 0, 0};
   int cc[3] = {0, 0, 0};
+  float qf[3] = {0.f, 0.f, 0.f};
   if (live) {
-    load_pt<GD>(sorted, p, q);
-    cell_of<GD>(q, g, cc);
+    load_pt32<GD>(sorted32, p, qf);
+    cell_of32<GD>(qf, g, cc);
   }
   constexpr int UNR = GD == 3 ? 4 : VCP_UNR2;  // binary32 candidates: half the registers per candidate in flight
   const int32_t myg = (GROUPED && live) ? sgroup[p] : 0;
   int cnt = 0, nrec = 0;
   const int NB = no.NB;
-  float qf[3] = {0.f, 0.f, 0.f};
-  if (live) load_pt32<GD>(sorted32, p, qf);
   if (live) for_rows<GD>(cc, g, cellstart, [&](uint32_t s, uint32_t e) {
     // batches of UNR candidates: UNR independent loads in flight per lane (the loop is latency bound), the
     // early exit is checked once per batch.  Candidates are screened on their binary32 copies (within_scr).
@@ -565,7 +578,7 @@ __global__ __launch_bounds__(TPB) void k_core(const double* __restrict__ sorted,
       }
 #pragma unroll
       for (int u = 0; u < UNR; u++) {
-        bool ok = (j + u < e) && within_scr<GD, METRIC>(qf, r[u], sc, q, sorted, j + u, thr);
+        bool ok = (j + u < e) && within_scr<GD, METRIC>(qf, r[u], sc, xs, (uint32_t)p, j + u, thr);
         if (GROUPED) ok = ok && gj[u] == myg;
         cnt += ok ? 1 : 0;
         if (ok && nrec < NB && j + u != (uint32_t)p) lnb[(nrec++) * TPB + threadIdx.x] = j + u;
@@ -682,8 +695,8 @@ __device__ __forceinline__ void tile_load(CoreTile<GD>& t, const float* __restri
 // hit beyond the masks that stays below min_pts (`rescan`) walks its rows again in global memory: rare.
 template <int GD, int METRIC>
 __device__ __forceinline__ void nbr_flush_masks(const NbrOut& no, uint32_t* lout, const uint32_t* hm, const uint32_t* rs,
-                                                const uint32_t* re, bool rescan, int nrec, const double* q, double thr,
-                                                const double* __restrict__ sorted, int64_t blk, int64_t p, bool live) {
+                                                const uint32_t* re, bool rescan, int nrec, double thr, const ExactSrc& xs,
+                                                int64_t blk, int64_t p, bool live) {
   if (no.NB == 0) return;
   constexpr int NR = CoreTile<GD>::NR;
   __shared__ uint32_t wtot[TPB / 64];
@@ -704,10 +717,12 @@ __device__ __forceinline__ void nbr_flush_masks(const NbrOut& no, uint32_t* lout
   if (live) no.off[p] = (uint16_t)pre;
   int k = 0;
   if (rescan) {
+    double q[3];
+    load_exact<GD>(xs, (uint32_t)p, q);
     for (int r = 0; r < NR; r++)
       for (uint32_t j = rs[r]; j < re[r] && k < nrec; j++) {
         double rr[3];
-        load_pt<GD>(sorted, j, rr);
+        load_exact<GD>(xs, j, rr);
         if (j != (uint32_t)p && within<METRIC>(q, rr, thr)) lout[pre + (k++)] = j;
       }
   } else {
@@ -727,7 +742,7 @@ __device__ __forceinline__ void nbr_flush_masks(const NbrOut& no, uint32_t* lout
 }
 
 template <int GD, int METRIC>
-__global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sorted, GridP g, double thr, int min_pts,
+__global__ __launch_bounds__(TPB) void k_core_lds(ExactSrc xs, GridP g, double thr, int min_pts,
                                                  const uint32_t* __restrict__ cellstart, uint8_t* __restrict__ flags,
                                                  uint32_t* __restrict__ parent, uint32_t* __restrict__ minord,
                                                  uint32_t* __restrict__ blkE, uint32_t* __restrict__ blkB, NbrOut no,
@@ -739,13 +754,11 @@ __global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sor
   const int64_t blk = xcd_block(gridDim.x);
   int64_t p = blk * TPB + threadIdx.x;
   const bool live = p < nin;
-  double q[3] = {0, 0, 0};
   int cc[3] = {0, 0, 0};
   float qf[3] = {0.f, 0.f, 0.f};
   if (live) {
-    load_pt<GD>(sorted, p, q);
     load_pt32<GD>(sorted32, p, qf);
-    cell_of<GD>(q, g, cc);
+    cell_of32<GD>(qf, g, cc);
   }
   uint32_t rs[NR], re[NR];
   const bool fits = tile_bounds<GD>(t, live, cc, g, cellstart, rs, re);
@@ -783,11 +796,13 @@ __global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sor
           nib &= lim;
           am &= nib;
           if (am != 0u) {
+            double q[3];
+            load_exact<GD>(xs, (uint32_t)p, q);
 #pragma unroll
             for (int u = 0; u < UNR; u++)
               if ((am >> u) & 1u) {
                 double rr[3];
-                load_pt<GD>(sorted, lo + j + u, rr);
+                load_exact<GD>(xs, lo + j + u, rr);
                 if (!within<METRIC>(q, rr, thr)) nib &= ~(1u << u);
               }
           }
@@ -810,7 +825,7 @@ __global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sor
         uint32_t nib = 0;
 #pragma unroll
         for (int u = 0; u < UNR; u++)
-          nib |= ((j + u < re[r]) && within_scr<GD, METRIC>(qf, rr[u], sc, q, sorted, j + u, thr)) ? (1u << u) : 0u;
+          nib |= ((j + u < re[r]) && within_scr<GD, METRIC>(qf, rr[u], sc, xs, (uint32_t)p, j + u, thr)) ? (1u << u) : 0u;
         cnt += __popc(nib);
         const uint32_t sh = j - rs[r];
         hm[r] |= sh < 32u ? nib << sh : 0u;
@@ -856,7 +871,7 @@ __global__ __launch_bounds__(TPB) void k_core_lds(const double* __restrict__ sor
     parent[p] = isE ? (uint32_t)p : NONE;
     minord[p] = NONE;
   }
-  nbr_flush_masks<GD, METRIC>(no, t.lout, hm, rs, re, rescan, nrec, q, thr, sorted, blk, p, live);
+  nbr_flush_masks<GD, METRIC>(no, t.lout, hm, rs, re, rescan, nrec, thr, xs, blk, p, live);
   wl_count(isE, isB, (uint32_t)blk, blkE, blkB);
 }
 
@@ -908,17 +923,17 @@ __device__ __forceinline__ uint32_t uf_link(uint32_t* parent, uint32_t ra, uint3
 // it finds at a SMALLER position (any such neighbour keeps the pointers decreasing; early exit).  Plain
 // stores, no atomics: each thread writes only its own parent and pointers only go down, so this is a forest.
 template <int GD, int METRIC, bool GROUPED>
-__global__ __launch_bounds__(TPB) void k_union_init(const double* __restrict__ sorted, GridP g, double thr,
+__global__ __launch_bounds__(TPB) void k_union_init(ExactSrc xs, GridP g, double thr,
                                                    const uint32_t* __restrict__ cellstart,
                                                    const int32_t* __restrict__ sgroup,
                                                    const uint8_t* __restrict__ flags, uint32_t* __restrict__ parent,
-                                                   WorkList wlE) {
+                                                   WorkList wlE, const float* __restrict__ sorted32, Screen sc) {
   const uint32_t p = wl_fetch(wlE);
   if (p == NONE) return;
-  double q[3];
+  float qf[3];
   int cc[3];
-  load_pt<GD>(sorted, p, q);
-  cell_of<GD>(q, g, cc);
+  load_pt32<GD>(sorted32, p, qf);
+  cell_of32<GD>(qf, g, cc);
   constexpr int UNR = GD == 3 ? VCP_UNR3 : VCP_UNR2;
   const int32_t myg = GROUPED ? sgroup[p] : 0;
   const uint32_t me = (uint32_t)p;
@@ -927,18 +942,18 @@ __global__ __launch_bounds__(TPB) void k_union_init(const double* __restrict__ s
     if (s >= me) return true;  // only smaller positions (pointers must decrease); runs come in any order
     if (e > me) e = me;
     for (uint32_t j0 = s; j0 < e; j0 += UNR) {
-      double rr[UNR][3];
+      float rr[UNR][3];
       bool cand[UNR];
 #pragma unroll
       for (int u = 0; u < UNR; u++) {
         const uint32_t jj = min(j0 + u, e - 1);
         cand[u] = (j0 + u < e) && (flags[jj] & F_EXPAND);
         if (GROUPED) cand[u] = cand[u] && sgroup[jj] == myg;
-        load_pt<GD>(sorted, jj, rr[u]);
+        load_pt32<GD>(sorted32, jj, rr[u]);
       }
 #pragma unroll
       for (int u = 0; u < UNR; u++)
-        if (first == me && cand[u] && within<METRIC>(q, rr[u], thr)) first = j0 + u;
+        if (first == me && cand[u] && within_scr<GD, METRIC>(qf, rr[u], sc, xs, me, j0 + u, thr)) first = j0 + u;
       if (first != me) return false;
     }
     return true;
@@ -1038,7 +1053,7 @@ __global__ __launch_bounds__(TPB) void k_flatten0(uint32_t* __restrict__ parent,
 // (Staging the parent words of a workgroup's three candidate rows in LDS, as the core count does with coordinates, was
 // measured: 282 us against 258 us -- the per-workgroup range reduction and barriers cost more than the L1 accesses saved.)
 template <int GD, int METRIC, bool GROUPED, bool PRE>
-__global__ __launch_bounds__(TPB) void k_union(const double* __restrict__ sorted, GridP g, double thr,
+__global__ __launch_bounds__(TPB) void k_union(ExactSrc xs, GridP g, double thr,
                                               const uint32_t* __restrict__ cellstart,
                                               const int32_t* __restrict__ sgroup, uint32_t* __restrict__ parent,
                                               WorkList wlE, const float* __restrict__ sorted32, Screen sc) {
@@ -1046,12 +1061,10 @@ __global__ __launch_bounds__(TPB) void k_union(const double* __restrict__ sorted
   if (p == NONE) return;
   constexpr int NR = GD == 3 ? 9 : 3;
   uint32_t rs[NR], re[NR];
-  double q[3];
   float qf[3];
   int cc[3];
-  load_pt<GD>(sorted, p, q);
   load_pt32<GD>(sorted32, p, qf);
-  cell_of<GD>(q, g, cc);
+  cell_of32<GD>(qf, g, cc);
   row_bounds<GD>(cc, g, cellstart, rs, re);
   constexpr int UNR = PRE ? VCP_UNRW : (GD == 3 ? VCP_UNR3 : VCP_UNR2);
   const int32_t myg = GROUPED ? sgroup[p] : 0;
@@ -1081,7 +1094,7 @@ __global__ __launch_bounds__(TPB) void k_union(const double* __restrict__ sorted
         if (PRE && (x == a0 || x == a1 || x == a2 || x == q0 || x == q1)) continue;
         if (GROUPED && sgroup[j] != myg) continue;
         if (PRE) load_pt32<GD>(sorted32, j, cf[u]);
-        if (!within_scr<GD, METRIC>(qf, cf[u], sc, q, sorted, j, thr)) continue;
+        if (!within_scr<GD, METRIC>(qf, cf[u], sc, xs, me, j, thr)) continue;
         if (!PRE) {
           // second hop: j's tree was hooked under my root by an earlier edge (one L2 load instead of two chases)
           const uint32_t x2 = ld_parent_cached(parent, x);
@@ -1193,24 +1206,24 @@ __device__ __forceinline__ void twice_add(unsigned twice, unsigned long long* __
 // twice[...] counts border points the C# main loop had already queried before their first cluster's
 // seed came up (BaseClass/DBImproved.cs:93-104 then :63-67)
 template <int GD, int METRIC, bool GROUPED>
-__global__ __launch_bounds__(TPB) void k_border(const double* __restrict__ sorted, GridP g, double thr,
+__global__ __launch_bounds__(TPB) void k_border(ExactSrc xs, GridP g, double thr,
                                                const uint32_t* __restrict__ cellstart,
                                                const int32_t* __restrict__ sgroup, const uint8_t* __restrict__ flags,
                                                const uint32_t* __restrict__ parent, const uint32_t* __restrict__ sord,
                                                const uint32_t* __restrict__ rootk, const uint32_t* __restrict__ clseed,
                                                uint32_t* __restrict__ labk, unsigned long long* __restrict__ counters,
                                                uint32_t* __restrict__ group_twice, WorkList wlB, uint32_t own_lo,
-                                               uint32_t own_span) {
+                                               uint32_t own_span, const float* __restrict__ sorted32, Screen sc) {
   const uint32_t p = wl_fetch(wlB);
   unsigned twice = 0;
   if (p != NONE) {
     const uint8_t fl = flags[p];
     uint32_t out = 0;
     {
-      double q[3];
+      float qf[3];
       int cc[3];
-      load_pt<GD>(sorted, p, q);
-      cell_of<GD>(q, g, cc);
+      load_pt32<GD>(sorted32, p, qf);
+      cell_of32<GD>(qf, g, cc);
       constexpr int UNR = VCP_UNRW;
       const int32_t myg = GROUPED ? sgroup[p] : 0;
       uint32_t mx = 0, mnk = NONE;
@@ -1228,9 +1241,9 @@ __global__ __launch_bounds__(TPB) void k_border(const double* __restrict__ sorte
             const uint32_t j = j0 + u, x = rk[u];
             if (j >= e || x == NONE || (x >= mnk && x < mx)) continue;
             if (GROUPED && sgroup[j] != myg) continue;
-            double rr[3];
-            load_pt<GD>(sorted, j, rr);
-            if (within<METRIC>(q, rr, thr)) {
+            float rr[3];
+            load_pt32<GD>(sorted32, j, rr);
+            if (within_scr<GD, METRIC>(qf, rr, sc, xs, p, j, thr)) {
               mx = max(mx, x + 1u);
               mnk = min(mnk, x);
             }
@@ -1724,6 +1737,13 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   const double min_w = range / 1048575.0;
   if (!(cellw >= min_w)) cellw = min_w;
   if (!(cellw > 0.0)) cellw = 1.0;
+  // The cells are taken from binary32 relative coordinates (grid_common.hpp: rel32): each is within 2^-23.9 of its
+  // magnitude of the exact difference, and wherever the cell index is not clamped that magnitude is below
+  // range + 2 cells.  Two points within eps on an axis must end up at most one cell apart: cellw >= eps + both roundings.
+  {
+    const double need = (eps + (range + 4.0 * cellw) * (1.0 / 4194304.0)) * (1.0 + 1.0 / 1048576.0);
+    if (std::isfinite(need) && !(cellw >= need)) cellw = need;
+  }
   int64_t ncells = 0;
   for (int it = 0; it < 400; it++) {
     ncells = 1;
@@ -1746,7 +1766,11 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   VCP_TRY(vcp_ensure(ctx, ctx->b_cellof, (size_t)n * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_rank, (size_t)n * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_pos, (size_t)n * 4));
-  VCP_TRY(vcp_ensure(ctx, ctx->b_sorted, (size_t)n * GD * 8));
+  // cell order comes from the two-level partition (gridbuild.hip) unless the grid is too large for its one-level coarse
+  // split; only the sort-based build and the staged calls keep a cell-ordered binary64 copy
+  const bool part = vcp_grid_partition_fits(n, g.ncells);
+  const bool staged = ext && ext->slab;
+  if (!part || staged) VCP_TRY(vcp_ensure(ctx, ctx->b_sorted, (size_t)n * GD * 8));
   VCP_TRY(vcp_ensure(ctx, ctx->b_sorted32, (size_t)n * (GD == 2 ? 2 : 4) * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_sidx, (size_t)n * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_flags, (size_t)n));
@@ -1790,7 +1814,7 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   // flags before the core count: the build stores the callers' isClassed bits; without them the core count starts every
   // byte itself and nothing has to be there
   const bool flags_set = d_in_classed != nullptr;
-  const bool part = vcp_grid_partition_fits(n, g.ncells);
+  ExactSrc xs{sorted, nullptr, GD};
   const bool part_out = part && !GROUPED && !d_ord && !(ext && ext->slab) && n <= ((int64_t)1 << 27);
   if (part) {
     if (!flags_set && GROUPED) VCP_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)n, st));  // bytes of excluded points
@@ -1806,13 +1830,18 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
     ga.d_ord = d_ord;
     ga.d_in_classed = d_in_classed;
     ga.cellstart = cellcnt;
-    ga.sorted = sorted;
+    ga.sidx = d_ord ? cellof : nullptr;  // the point's index where sord holds the caller's list position instead
     ga.sorted32 = sorted32;
     ga.sord = sord;
     ga.sgroup = sgroup;
     ga.flags = flags;
     ga.pos = part_out ? nullptr : pos;
     VCP_TRY(vcp_grid_build_partition(ctx, ga));
+    xs = ExactSrc{d_coords, d_ord ? cellof : sord, stride};
+    if (staged) {
+      hipLaunchKernelGGL(k_exact_copy<GD>, dim3(nb), dim3(TPB), 0, st, xs, cellcnt, g.ncells, sorted);
+      xs = ExactSrc{sorted, nullptr, GD};
+    }
   } else {
     vcp_phase(ctx, "cell_key");
     VCP_TRY(vcp_ensure(ctx, ctx->b_skey, (size_t)n * 4));
@@ -1868,10 +1897,10 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   }
   const size_t lds_nb = (size_t)no.NB * TPB * 4;
   if constexpr (GD == 2 && !GROUPED)
-    hipLaunchKernelGGL((k_core_lds<GD, METRIC>), dim3(nb), dim3(TPB), 0, st, sorted, g, thr, min_pts, cellcnt, flags, parent,
+    hipLaunchKernelGGL((k_core_lds<GD, METRIC>), dim3(nb), dim3(TPB), 0, st, xs, g, thr, min_pts, cellcnt, flags, parent,
                        minord, blkE, blkB, no, sorted32, sc, flags_set);
   else
-    hipLaunchKernelGGL((k_core<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 2 * lds_nb, st, sorted, g, thr, min_pts, cellcnt,
+    hipLaunchKernelGGL((k_core<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 2 * lds_nb, st, xs, g, thr, min_pts, cellcnt,
                        sgroup, flags, parent, minord, blkE, blkB, no, sorted32, sc, flags_set);
   // ONE scan over both count arrays (they are adjacent): the B half comes out offset by everything before it, which
   // its readers take off again (scan[0]); the two pad words between the halves are never written and cancel the same way
@@ -1888,15 +1917,15 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
     hipLaunchKernelGGL(k_flatten0<true>, dim3(nbl), dim3(TPB), 0, st, parent, wlE, flags, no);
     hipLaunchKernelGGL(k_flatten0<false>, dim3(nbl), dim3(TPB), 0, st, parent, wlE, flags, no);
   } else if (GD == 2) {
-    hipLaunchKernelGGL((k_union_init<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup,
-                       flags, parent, wlE);
+    hipLaunchKernelGGL((k_union_init<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, xs, g, thr, cellcnt, sgroup,
+                       flags, parent, wlE, sorted32, sc);
     hipLaunchKernelGGL(k_flatten0<false>, dim3(nbl), dim3(TPB), 0, st, parent, wlE, flags, no);
   }
   if (pre)
-    hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED, true>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup,
+    hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED, true>), dim3(nbl), dim3(TPB), 0, st, xs, g, thr, cellcnt, sgroup,
                        parent, wlE, sorted32, sc);
   else
-    hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED, false>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup,
+    hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED, false>), dim3(nbl), dim3(TPB), 0, st, xs, g, thr, cellcnt, sgroup,
                        parent, wlE, sorted32, sc);
   vcp_phase(ctx, "flatten_number");
   hipLaunchKernelGGL(k_flatten, dim3(nbl), dim3(TPB), 0, st, parent, sord, minord, wlE);
@@ -1921,6 +1950,7 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
     ss.n_comp = hn[0];
     ss.g = g;
     ss.thr = thr;
+    ss.sc = sc;
     ss.nb = nb;
     if (cf_out) *cf_out = (int32_t)hn[0];
     return VCP_OK;
@@ -1938,8 +1968,9 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
     hipLaunchKernelGGL(k_border_list<GROUPED>, dim3(nbl), dim3(TPB), 0, st, sgroup, flags, sord, rootk, clseed, labk, counters,
                        GROUPED ? ext->d_group_twice : nullptr, no, wlB);
   else
-    hipLaunchKernelGGL((k_border<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, sorted, g, thr, cellcnt, sgroup, flags,
-                       parent, sord, rootk, clseed, labk, counters, GROUPED ? ext->d_group_twice : nullptr, wlB, 0u, NONE);
+    hipLaunchKernelGGL((k_border<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, xs, g, thr, cellcnt, sgroup, flags,
+                       parent, sord, rootk, clseed, labk, counters, GROUPED ? ext->d_group_twice : nullptr, wlB, 0u, NONE,
+                       sorted32, sc);
   if (part_out) {
     GridOutputArgs oa;
     oa.n = n;
@@ -2019,8 +2050,9 @@ int run_slab_finish(vcp_ctx* ctx, const SlabState& ss, const uint32_t* d_map_rep
                      (uint32_t)ss.n_comp, rootk, counters);
   vcp_phase(ctx, "border");
   hipLaunchKernelGGL(k_labk_rest, dim3(nb), dim3(TPB), 0, st, flags, parent, rootk, labk, cellcnt, g.ncells);
-  hipLaunchKernelGGL((k_border<GD, METRIC, false>), dim3(nbl), dim3(TPB), 0, st, sorted, g, ss.thr, cellcnt, nullptr, flags,
-                     parent, sord, rootk, clseed, labk, counters, nullptr, wlB, own_lo, own_span);
+  hipLaunchKernelGGL((k_border<GD, METRIC, false>), dim3(nbl), dim3(TPB), 0, st, ExactSrc{sorted, nullptr, GD}, g, ss.thr,
+                     cellcnt, nullptr, flags, parent, sord, rootk, clseed, labk, counters, nullptr, wlB, own_lo, own_span,
+                     ctx->b_sorted32.as<float>(), ss.sc);
   vcp_phase(ctx, "output");
   hipLaunchKernelGGL(k_slab_output, dim3(nb), dim3(TPB), 0, st, n, pos, labk, d_tab_gid, d_labels, d_is_classed);
   VCP_HIP(ctx, hipGetLastError());

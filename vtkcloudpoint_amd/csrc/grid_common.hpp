@@ -26,11 +26,22 @@ __device__ __forceinline__ uint32_t cell_id(const GridP& g, int cx, int cy, int 
   return id;
 }
 
-__device__ __forceinline__ int cell_coord(double x, double mn, double inv_h, int D) {
-  double u = (x - mn) * inv_h;
+// The grid bins on the BINARY32 value of the coordinate relative to the grid origin -- the same number the screening
+// copies (sorted32) hold -- so a kernel that has only the 8/16-byte screening copy of a point knows its cell, and the
+// partition build can carry binary32 records.  rel32 is monotone in x, hence so is the cell index; the cell width
+// includes the rounding of two such values (run(): cellw), so two points within eps of each other on an axis still
+// land in the same or in adjacent cells.
+__device__ __forceinline__ float rel32(double x, double mn) { return (float)(x - mn); }
+
+__device__ __forceinline__ int cell_coord32(float f, double inv_h, int D) {
+  double u = (double)f * inv_h;
   if (u >= 0.0 && u < (double)D) return (int)u;
   if (u >= (double)D) return D - 1;
   return 0;  // below the minimum or NaN
+}
+
+__device__ __forceinline__ int cell_coord(double x, double mn, double inv_h, int D) {
+  return cell_coord32(rel32(x, mn), inv_h, D);
 }
 
 template <int GD>
@@ -79,6 +90,15 @@ __device__ __forceinline__ uint32_t cell_of(const double* q, const GridP& g, int
   return cell_id<GD>(g, cc[0], cc[1], cc[2]);
 }
 
+template <int GD>
+__device__ __forceinline__ uint32_t cell_of32(const float* qf, const GridP& g, int* cc) {
+  cc[0] = cell_coord32(qf[0], g.inv_h, g.D[0]);
+  cc[1] = cell_coord32(qf[1], g.inv_h, g.D[1]);
+  cc[2] = 0;
+  if (GD == 3) cc[2] = cell_coord32(qf[2], g.inv_h, g.D[2]);
+  return cell_id<GD>(g, cc[0], cc[1], cc[2]);
+}
+
 // ---- binary32 screening of the distance predicate ----------------------------------------------------------
 // The search kernels decide `d(p, j) <= eps` on binary32 copies of the coordinates, taken relative to the grid origin,
 // wherever that decision is provably the binary64 one: value <= lo -> inside, value > hi -> outside, anything else
@@ -105,11 +125,27 @@ __device__ __forceinline__ void load_pt32(const float* __restrict__ c, int64_t i
 template <int GD>
 __device__ __forceinline__ void store_pt32(float* __restrict__ c, int64_t i, const double* q, const GridP& g) {
   if (GD == 2) {
-    *reinterpret_cast<float2*>(c + 2 * i) = make_float2((float)(q[0] - g.mn[0]), (float)(q[1] - g.mn[1]));
+    *reinterpret_cast<float2*>(c + 2 * i) = make_float2(rel32(q[0], g.mn[0]), rel32(q[1], g.mn[1]));
   } else {
     *reinterpret_cast<float4*>(c + 4 * i) =
-        make_float4((float)(q[0] - g.mn[0]), (float)(q[1] - g.mn[1]), (float)(q[2] - g.mn[2]), 0.0f);
+        make_float4(rel32(q[0], g.mn[0]), rel32(q[1], g.mn[1]), rel32(q[2], g.mn[2]), 0.0f);
   }
+}
+
+// Where the binary64 coordinates of cell-ordered position p are: a cell-ordered copy (idx == NULL, the sort-based
+// build and the staged multi-GPU calls), or the CALLER's array through the point's index (the partition build carries
+// binary32 records only).  Read by the exact re-test of a pair the binary32 screen cannot decide -- a handful per
+// million candidates on real-valued clouds -- so the gather costs nothing there; on inputs where many pairs sit exactly
+// on the threshold (lattices with eps on the lattice) it is the price of the lighter build.
+struct ExactSrc {
+  const double* base;
+  const uint32_t* idx;
+  int stride;
+};
+template <int GD>
+__device__ __forceinline__ void load_exact(const ExactSrc& xs, uint32_t p, double* q) {
+  const int64_t i = xs.idx ? (int64_t)xs.idx[p] : (int64_t)p;
+  load_in<GD>(xs.base, i, xs.stride, q);
 }
 
 }  // namespace vcpg
@@ -129,9 +165,9 @@ struct GridBuildArgs {
   const uint8_t* d_in_classed = nullptr;    // NULL = flags are zero-filled by the caller
   // outputs (cell order unless noted)
   uint32_t* cellstart = nullptr;  // [ncells + 1]
-  double* sorted = nullptr;       // [nin * gd]
-  float* sorted32 = nullptr;      // [nin * (gd == 2 ? 2 : 4)] binary32 copies relative to g.mn (screening)
-  uint32_t* sord = nullptr;       // [nin]
+  float* sorted32 = nullptr;      // [nin * (gd == 2 ? 2 : 4)] binary32 coordinates relative to g.mn (binning, screening)
+  uint32_t* sord = nullptr;       // [nin] list position (d_ord of the point's index)
+  uint32_t* sidx = nullptr;       // [nin] the point's index in d_coords; NULL = not wanted (it is sord without d_ord)
   int32_t* sgroup = nullptr;      // [nin], grouped only
   uint8_t* flags = nullptr;       // [nin], written only with d_in_classed
   uint32_t* pos = nullptr;        // [n] caller order, NONE for left-out points; NULL = not wanted

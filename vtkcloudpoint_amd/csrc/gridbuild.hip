@@ -2,18 +2,21 @@
 //
 // The round-1 build sorted (cell id, index) pairs with a library radix sort and then gathered the coordinates by
 // index: every gathered point paid a 128-byte line for 16 bytes (3.7x the algorithmic traffic), and the output pass
-// paid the same on the way back (9x).  Here the coordinates TRAVEL with the index:
+// paid the same on the way back (9x).  Here a 16-byte record TRAVELS with the index: the point's binary32 coordinates
+// relative to the grid origin -- the values the grid bins on and the search kernels screen with (grid_common.hpp:
+// rel32) -- and its index.  The binary64 coordinates stay where the caller put them; the exact re-test of a screened
+// pair reads them by index (ExactSrc).
 //
 //   k_part_hist     per chunk of >= 8192 points: bucket histogram in LDS (bucket = 2^csh consecutive cell ids, i.e. a band
 //                   of grid rows) -> counts[bucket][chunk]
 //   (scan)          exclusive scan of counts in bucket-major order = where each chunk's share of each bucket starts
 //   k_part_scatter  per chunk: the scanned counts become per-bucket cursors in LDS; one returning LDS atomic per point
-//                   gives the slot of its record (x, y[, z], index) in the bucket-major record arrays -- each chunk
-//                   owns a contiguous run per bucket, so partial lines are completed in the writing XCD's L2
+//                   gives the slot of its record in the bucket-major record array -- each chunk owns a contiguous run
+//                   per bucket, so partial lines are completed in the writing XCD's L2
 //   k_part_fine     one workgroup per bucket: count the bucket's records per cell in LDS, scan, store the bucket's
-//                   slice of the cell table coalesced (written exactly once, never zero-filled), then place every
-//                   record at cellstart + rank: coordinates, list position, and the optional per-point extras.  The
-//                   scattered stores stay inside the bucket's own window of the cell-ordered arrays (L2-resident).
+//                   slice of the cell table coalesced (written exactly once, never zero-filled), then assemble the
+//                   bucket in LDS in its final order and store it as full lines: binary32 coordinates, list position,
+//                   and the optional per-point extras.
 //
 // and back (vcp_grid_output_partition): (list position, label word) pairs partitioned by windows of 2^OWSH list
 // positions, every window then written by workgroups that share an XCD (b and b+8 share an L2).
@@ -32,32 +35,43 @@ constexpr int PCH_MIN = 8192;      // smallest chunk
 constexpr int FT = 1024;           // threads per workgroup, fine pass
 constexpr uint32_t MAXB = 8192;    // buckets (LDS histogram of the coarse passes: 32 KB)
 // fine pass: a bucket of at most wcap records is staged in LDS in its final order (counters + staging <= 160 KB)
-constexpr uint32_t wcap(int gd) { return gd == 2 ? 4096u : 2816u; }
+constexpr uint32_t wcap(int) { return 4096u; }
 
-// One record of the bucket-major intermediate: 32 bytes, so that a lane's store is one contiguous 32-byte piece of a
-// line (measured on MI355X, tools/micro/part_bench.hip: 0.26 ms for 10 M records into 4096 buckets against 0.33 ms
-// with the coordinates and the index in separate arrays -- a divergent store costs per instruction, not per byte).
-struct __attribute__((aligned(32))) Rec {
-  double x, y, z;
-  uint32_t idx, pad;
-};
+// One record of the bucket-major intermediate: 16 bytes = the binary32 coordinates relative to the grid origin (what
+// the grid bins on and what the search kernels screen with, grid_common.hpp: rel32) + the point's index; in 2-D the
+// fourth word carries the cell id, in 3-D the fine pass recomputes it from the three coordinates.  The binary64
+// coordinates do NOT travel: the exact re-test of a screened pair (rare) reads them from the caller's array by index.
+// One 16-byte store per lane (a divergent store costs per instruction and per line touched -- tools/micro/part_bench.hip:
+// 10 M records into 4096 buckets take 0.23 ms at 16 B, 0.28 ms at 32 B, 0.33 ms as separate 16 + 4 B arrays).
+typedef float4 Rec;
 
 template <int GD>
-__device__ __forceinline__ void rec_store(Rec* __restrict__ r, uint32_t slot, const double* q, uint32_t idx) {
-  double4 v;
-  v.x = q[0];
-  v.y = q[1];
-  v.z = GD == 3 ? q[2] : 0.0;
-  v.w = __hiloint2double(0, (int)idx);
-  *reinterpret_cast<double4*>(r + slot) = v;
+__device__ __forceinline__ Rec rec_make(const float* qf, uint32_t idx, uint32_t cell) {
+  return GD == 2 ? make_float4(qf[0], qf[1], __uint_as_float(idx), __uint_as_float(cell))
+                 : make_float4(qf[0], qf[1], qf[2], __uint_as_float(idx));
 }
+// -> cell id; idx = the point's index
 template <int GD>
-__device__ __forceinline__ uint32_t rec_load(const Rec* __restrict__ r, uint32_t slot, double* q) {
-  const double4 v = *reinterpret_cast<const double4*>(r + slot);
-  q[0] = v.x;
-  q[1] = v.y;
-  if (GD == 3) q[2] = v.z;
-  return (uint32_t)__double2loint(v.w);
+__device__ __forceinline__ uint32_t rec_cell(const Rec& r, const GridP& g, uint32_t& idx) {
+  if (GD == 2) {
+    idx = __float_as_uint(r.z);
+    return __float_as_uint(r.w);
+  }
+  idx = __float_as_uint(r.w);
+  const float qf[3] = {r.x, r.y, r.z};
+  int cc[3];
+  return cell_of32<3>(qf, g, cc);
+}
+
+// caller-order point i -> its binary32 relative coordinates and cell
+template <int GD>
+__device__ __forceinline__ uint32_t point_cell(const double* __restrict__ c, int64_t i, int stride, const GridP& g, float* qf) {
+  double q[3];
+  int cc[3];
+  load_in<GD>(c, i, stride, q);
+#pragma unroll
+  for (int a = 0; a < GD; a++) qf[a] = rel32(q[a], g.mn[a]);
+  return cell_of32<GD>(qf, g, cc);
 }
 
 struct PartGeom {
@@ -103,10 +117,8 @@ __global__ __launch_bounds__(PT) void k_part_hist(const double* __restrict__ c, 
       const int gg = group[i];
       if (gg < glo || gg >= ghi) continue;
     }
-    double q[3];
-    int cc[3];
-    load_in<GD>(c, i, stride, q);
-    atomicAdd(&h[cell_of<GD>(q, g, cc) >> csh], 1u);
+    float qf[3];
+    atomicAdd(&h[point_cell<GD>(c, i, stride, g, qf) >> csh], 1u);
   }
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < B; k += PT) counts[(size_t)k * nchunk + blockIdx.x] = h[k];
@@ -134,10 +146,9 @@ __global__ __launch_bounds__(PT) void k_part_scatter(const double* __restrict__ 
         continue;
       }
     }
-    double q[3];
-    int cc[3];
-    load_in<GD>(c, i, stride, q);
-    rec_store<GD>(rec, atomicAdd(&h[cell_of<GD>(q, g, cc) >> csh], 1u), q, (uint32_t)i);
+    float qf[3];
+    const uint32_t cell = point_cell<GD>(c, i, stride, g, qf);
+    rec[atomicAdd(&h[cell >> csh], 1u)] = rec_make<GD>(qf, (uint32_t)i, cell);
   }
 }
 
@@ -152,32 +163,37 @@ __device__ __forceinline__ uint32_t padded(uint32_t i) { return i + (i >> 5); }
 // final position start[cell] + rank is known without a cursor, and walks its records once per window of WCAP
 // positions (the records of a bucket stay L2-resident).
 template <int GD, bool GROUPED>
-__device__ __forceinline__ void fine_flush(uint32_t s0, uint32_t m, const double* sxy, const uint32_t* sidx, const GridP& g,
+__device__ __forceinline__ void fine_flush(uint32_t s0, uint32_t m, const float* s32, const uint32_t* sidx,
                                            const uint32_t* __restrict__ ord, const uint8_t* __restrict__ in_classed,
-                                           const int32_t* __restrict__ group, double* __restrict__ sorted,
-                                           float* __restrict__ sorted32, uint32_t* __restrict__ sord,
+                                           const int32_t* __restrict__ group, float* __restrict__ sorted32,
+                                           uint32_t* __restrict__ sord, uint32_t* __restrict__ sidx_out,
                                            int32_t* __restrict__ sgroup, uint8_t* __restrict__ flags,
                                            uint32_t* __restrict__ pos) {
   if (GD == 2) {
-    const double2* src = reinterpret_cast<const double2*>(sxy);
-    double2* dst = reinterpret_cast<double2*>(sorted) + s0;
-    float2* dst32 = reinterpret_cast<float2*>(sorted32) + s0;
-    for (uint32_t k = threadIdx.x; k < m; k += FT) {
-      const double2 v = src[k];
-      dst[k] = v;
-      dst32[k] = make_float2((float)(v.x - g.mn[0]), (float)(v.y - g.mn[1]));
-    }
+    const float2* src = reinterpret_cast<const float2*>(s32);
+    float2* dst = reinterpret_cast<float2*>(sorted32) + s0;
+    for (uint32_t k = threadIdx.x; k < m; k += FT) dst[k] = src[k];
   } else {
-    for (uint32_t k = threadIdx.x; k < 3 * m; k += FT) sorted[(size_t)3 * s0 + k] = sxy[k];
-    for (uint32_t k = threadIdx.x; k < m; k += FT) store_pt32<GD>(sorted32, (int64_t)s0 + k, sxy + (size_t)3 * k, g);
+    const float4* src = reinterpret_cast<const float4*>(s32);
+    float4* dst = reinterpret_cast<float4*>(sorted32) + s0;
+    for (uint32_t k = threadIdx.x; k < m; k += FT) dst[k] = src[k];
   }
   for (uint32_t k = threadIdx.x; k < m; k += FT) {
     const uint32_t i = sidx[k], p = s0 + k;
     sord[p] = ord ? ord[i] : i;
+    if (sidx_out) sidx_out[p] = i;
     if (GROUPED) sgroup[p] = group[i];
     if (in_classed) flags[p] = in_classed[i] ? F_CLASSED : 0;
     if (pos) pos[i] = p;
   }
+}
+
+// staging store of one record at window slot p
+template <int GD>
+__device__ __forceinline__ void stage_put(float* s32, uint32_t* sidx, uint32_t p, const Rec& r, uint32_t idx) {
+  if (GD == 2) reinterpret_cast<float2*>(s32)[p] = make_float2(r.x, r.y);
+  else reinterpret_cast<float4*>(s32)[p] = make_float4(r.x, r.y, r.z, 0.0f);
+  sidx[p] = idx;
 }
 
 template <int GD, bool GROUPED>
@@ -186,17 +202,18 @@ __global__ __launch_bounds__(FT) void k_part_fine(const Rec* __restrict__ rec, u
                                                  uint32_t nchunk, uint32_t B, uint32_t csh, GridP g,
                                                  const uint32_t* __restrict__ ord, const uint8_t* __restrict__ in_classed,
                                                  const int32_t* __restrict__ group, uint32_t* __restrict__ cellstart,
-                                                 double* __restrict__ sorted, float* __restrict__ sorted32,
-                                                 uint32_t* __restrict__ sord, int32_t* __restrict__ sgroup,
+                                                 float* __restrict__ sorted32, uint32_t* __restrict__ sord,
+                                                 uint32_t* __restrict__ sidx_out, int32_t* __restrict__ sgroup,
                                                  uint8_t* __restrict__ flags, uint32_t* __restrict__ pos) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   __shared__ uint32_t wsum[FT / 64];
   const uint32_t b = blockIdx.x;
   constexpr uint32_t WCAP = wcap(GD);
+  constexpr uint32_t FPR = GD == 2 ? 2 : 4;  // staged floats per record
   const uint32_t CPB = 1u << csh;
   uint32_t* cnt = reinterpret_cast<uint32_t*>(lds);                                  // [padded(CPB)]
-  double* sxy = reinterpret_cast<double*>(lds + (((size_t)padded(CPB) + 4) & ~3ull) * 4);  // [WCAP * GD]
-  uint32_t* sidx = reinterpret_cast<uint32_t*>(sxy + (size_t)WCAP * GD);              // [WCAP]
+  float* s32 = reinterpret_cast<float*>(lds + (((size_t)padded(CPB) + 4) & ~3ull) * 4);  // [WCAP * FPR]
+  uint32_t* sidx = reinterpret_cast<uint32_t*>(s32 + (size_t)WCAP * FPR);            // [WCAP]
   const uint32_t c0 = b << csh;
   const uint32_t s = base[(size_t)b * nchunk];
   const uint32_t e = (b + 1 < B) ? base[(size_t)(b + 1) * nchunk] : *total;
@@ -205,10 +222,8 @@ __global__ __launch_bounds__(FT) void k_part_fine(const Rec* __restrict__ rec, u
   for (uint32_t k = threadIdx.x; k < padded(CPB); k += FT) cnt[k] = 0;
   __syncthreads();
   for (uint32_t j = s + threadIdx.x; j < e; j += FT) {
-    double q[3];
-    int cc[3];
-    rec_load<GD>(rec, j, q);
-    uint32_t* slot = &cnt[padded(cell_of<GD>(q, g, cc) - c0)];
+    uint32_t i;
+    uint32_t* slot = &cnt[padded(rec_cell<GD>(rec[j], g, i) - c0)];
     if (big) rk[j] = atomicAdd(slot, 1u);  // rank inside the cell
     else atomicAdd(slot, 1u);
   }
@@ -242,30 +257,24 @@ __global__ __launch_bounds__(FT) void k_part_fine(const Rec* __restrict__ rec, u
   if (!big) {
     // one window: the scanned counters serve as per-cell cursors
     for (uint32_t j = s + threadIdx.x; j < e; j += FT) {
-      double q[3];
-      int cc[3];
-      const uint32_t i = rec_load<GD>(rec, j, q);
-      const uint32_t p = atomicAdd(&cnt[padded(cell_of<GD>(q, g, cc) - c0)], 1u) - s;
-      store_pt<GD>(sxy, p, q);
-      sidx[p] = i;
+      const Rec r = rec[j];
+      uint32_t i;
+      const uint32_t p = atomicAdd(&cnt[padded(rec_cell<GD>(r, g, i) - c0)], 1u) - s;
+      stage_put<GD>(s32, sidx, p, r, i);
     }
     __syncthreads();
-    fine_flush<GD, GROUPED>(s, m, sxy, sidx, g, ord, in_classed, group, sorted, sorted32, sord, sgroup, flags, pos);
+    fine_flush<GD, GROUPED>(s, m, s32, sidx, ord, in_classed, group, sorted32, sord, sidx_out, sgroup, flags, pos);
     return;
   }
   for (uint32_t w0 = 0; w0 < m; w0 += WCAP) {
     for (uint32_t j = s + threadIdx.x; j < e; j += FT) {
-      double q[3];
-      int cc[3];
-      const uint32_t i = rec_load<GD>(rec, j, q);
-      const uint32_t p = cnt[padded(cell_of<GD>(q, g, cc) - c0)] + rk[j] - s - w0;  // wraps below the window
-      if (p < WCAP) {
-        store_pt<GD>(sxy, p, q);
-        sidx[p] = i;
-      }
+      const Rec r = rec[j];
+      uint32_t i;
+      const uint32_t p = cnt[padded(rec_cell<GD>(r, g, i) - c0)] + rk[j] - s - w0;  // wraps below the window
+      if (p < WCAP) stage_put<GD>(s32, sidx, p, r, i);
     }
     __syncthreads();
-    fine_flush<GD, GROUPED>(s + w0, min(WCAP, m - w0), sxy, sidx, g, ord, in_classed, group, sorted, sorted32, sord, sgroup,
+    fine_flush<GD, GROUPED>(s + w0, min(WCAP, m - w0), s32, sidx, ord, in_classed, group, sorted32, sord, sidx_out, sgroup,
                             flags, pos);
     __syncthreads();
   }
@@ -388,7 +397,7 @@ int build(vcp_ctx* ctx, const GridBuildArgs& a) {
   Rec* rec = ctx->b_rec.as<Rec>();
   const size_t lds_h = (size_t)pg.B * 4;
   const uint32_t CPB = 1u << pg.csh;
-  const size_t lds_f = ((((size_t)CPB + CPB / 32) + 4) & ~3ull) * 4 + (size_t)wcap(GD) * (GD * 8 + 4);
+  const size_t lds_f = ((((size_t)CPB + CPB / 32) + 4) & ~3ull) * 4 + (size_t)wcap(GD) * ((GD == 2 ? 8 : 16) + 4);
   VCP_TRY(allow_lds(ctx, k_part_fine<GD, GROUPED>, lds_f));
   vcp_phase(ctx, "part_hist");
   hipLaunchKernelGGL((k_part_hist<GD, GROUPED>), dim3(pg.nchunk), dim3(PT), lds_h, st, a.d_coords, a.n, a.stride, a.g,
@@ -401,7 +410,7 @@ int build(vcp_ctx* ctx, const GridBuildArgs& a) {
   VCP_TRY(vcp_ensure(ctx, ctx->b_rank, (size_t)a.n * 4));  // ranks inside the cell, written for large buckets only
   hipLaunchKernelGGL((k_part_fine<GD, GROUPED>), dim3(pg.B), dim3(FT), lds_f, st, rec, ctx->b_rank.as<uint32_t>(), counts,
                      total, pg.nchunk, pg.B,
-                     pg.csh, a.g, a.d_ord, a.d_in_classed, a.d_group, a.cellstart, a.sorted, a.sorted32, a.sord, a.sgroup,
+                     pg.csh, a.g, a.d_ord, a.d_in_classed, a.d_group, a.cellstart, a.sorted32, a.sord, a.sidx, a.sgroup,
                      a.flags, a.pos);
   VCP_HIP(ctx, hipGetLastError());
   return VCP_OK;

@@ -112,6 +112,12 @@ __global__ __launch_bounds__(ITPB) void k_model32(const double* __restrict__ m, 
 // scalar load an L2 round trip, 30x slower than the tiled form.
 // NNMODE 2: the model has been binned (nngrid.hpp): every lane searches the cells round its own transformed point --
 // O(1) candidates per data point instead of the whole model, same exact binary64 decision and tie rule.
+struct StepArgs {
+  long long nd;
+  double tol;
+  int stop_rule, max_iter, mode;
+};
+
 constexpr int MTILE = 1024;
 template <int TB, int NNMODE>
 __global__ __launch_bounds__(TB) void k_icp_pass(const double* __restrict__ model, const float4* __restrict__ model32,
@@ -311,6 +317,158 @@ __global__ __launch_bounds__(TB) void k_icp_pass(const double* __restrict__ mode
   }
 }
 
+// ---- small models (nm <= 512: MainForm's 100 truths, C3) ---------------------------------------------------
+// The same pass with the screening loop reshaped for the VALU, which bounds it at 1 M x 100:
+//   * every lane works TWO data points at once, so the three FMAs of a score are packed binary32 operations
+//     (v_pk_fma_f32: two points per instruction against the one wave-uniform model point from the scalar cache);
+//   * the model index rides in the low `ib` mantissa bits of the score, so "smallest and second smallest score and
+//     the index of the smallest" is one v_and_or, one v_med3 and one v_min per pair instead of a compare, a min and
+//     three selects.  Replacing the low bits moves a score by at most 2^(ib-24) of its magnitude (<= 4.5 S^2); the
+//     ambiguity bound grows by twice that: (54 + 9 * 2^ib) u S^2, rounded up to a power of two on the host (tolk).
+//     A point whose two best scores are closer than the bound is decided in binary64 exactly as before.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// min of two scores as ONE instruction: fminf() first quiets both operands (a v_max x, x each) for IEEE signalling-NaN
+// semantics, doubling the cost of the hottest statement; NaN scores never reach the result (see tol2 below)
+__device__ __forceinline__ float min_raw(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+template <int TB>
+__global__ __launch_bounds__(TB) void k_icp_pass_small(const double* __restrict__ model, const float4* __restrict__ model32,
+                                                      int nm, const double* __restrict__ data, int64_t nd,
+                                                      const IcpState* __restrict__ st, double* __restrict__ partial,
+                                                      int32_t* __restrict__ nn, uint32_t imask, double tolk) {
+  if (st->done) return;
+  double R[9], T[3];
+#pragma unroll
+  for (int k = 0; k < 9; k++) R[k] = st->R[k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) T[k] = st->T[k];
+  const double cen0 = st->cen[0], cen1 = st->cen[1], cen2 = st->cen[2], mmax = st->mmax;
+  double s[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) s[k] = 0.0;
+  const int64_t half = (nd + 1) >> 1;  // lane v works points v and v + half
+  for (int64_t base = (int64_t)blockIdx.x * TB; base < half; base += (int64_t)gridDim.x * TB) {  // uniform trip count
+    const int64_t v = base + threadIdx.x;
+    int64_t idx[2] = {v, v + half};
+    bool live[2] = {v < half, v < half && v + half < nd};
+    double p[2][3];
+    float q[2][3], tol2[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int64_t il = live[h] ? idx[h] : nd - 1;  // idle slots recompute the last point, unused
+      const double d0 = data[3 * il], d1 = data[3 * il + 1], d2 = data[3 * il + 2];
+      // TransPoint: r = R*p accumulated k ascending from 0 (Matrix.StupidMultiply), then + T
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        double acc = 0.0;
+        acc += R[3 * r] * d0;
+        acc += R[3 * r + 1] * d1;
+        acc += R[3 * r + 2] * d2;
+        p[h][r] = acc + T[r];
+      }
+      const double pc0 = p[h][0] - cen0, pc1 = p[h][1] - cen1, pc2 = p[h][2] - cen2;
+      q[h][0] = (float)pc0;
+      q[h][1] = (float)pc1;
+      q[h][2] = (float)pc2;
+      const double S = fmax(mmax, fmax(fabs(pc0), fmax(fabs(pc1), fabs(pc2))));
+      const float t2 = (float)(S * S * tolk) * 1.0001f;
+      // scores are bounded by 4.5 S^2: beyond binary32 range (or NaN) the point goes to the exact scan
+      tol2[h] = (float)(S * S) < 1.0e37f ? t2 : NAN;
+    }
+    const f32x2 nq0 = {-q[0][0], -q[1][0]}, nq1 = {-q[0][1], -q[1][1]}, nq2 = {-q[0][2], -q[1][2]};
+    float b1[2] = {INFINITY, INFINITY}, b2[2] = {INFINITY, INFINITY};
+    // the mask lives in a VGPR so that (score & keep) | j is ONE v_and_or_b32 (a VOP3 reads one scalar operand: j)
+    uint32_t keep;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(keep) : "s"(~imask));
+    int j = 0;
+    for (; j + 1 < nm; j += 2) {
+      const float4 ma = model32[j], mb = model32[j + 1];
+      const f32x2 sa = __builtin_elementwise_fma(nq0, (f32x2)(ma.x), __builtin_elementwise_fma(nq1, (f32x2)(ma.y),
+                       __builtin_elementwise_fma(nq2, (f32x2)(ma.z), (f32x2)(ma.w))));
+      const f32x2 sb = __builtin_elementwise_fma(nq0, (f32x2)(mb.x), __builtin_elementwise_fma(nq1, (f32x2)(mb.y),
+                       __builtin_elementwise_fma(nq2, (f32x2)(mb.z), (f32x2)(mb.w))));
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const float ta = __uint_as_float((__float_as_uint(sa[h]) & keep) | (uint32_t)j);
+        const float tb = __uint_as_float((__float_as_uint(sb[h]) & keep) | (uint32_t)(j + 1));
+        b2[h] = __builtin_amdgcn_fmed3f(b1[h], b2[h], ta);
+        b1[h] = min_raw(b1[h], ta);
+        b2[h] = __builtin_amdgcn_fmed3f(b1[h], b2[h], tb);
+        b1[h] = min_raw(b1[h], tb);
+      }
+    }
+    if (j < nm) {
+      const float4 ma = model32[j];
+      const f32x2 sa = __builtin_elementwise_fma(nq0, (f32x2)(ma.x), __builtin_elementwise_fma(nq1, (f32x2)(ma.y),
+                       __builtin_elementwise_fma(nq2, (f32x2)(ma.z), (f32x2)(ma.w))));
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const float ta = __uint_as_float((__float_as_uint(sa[h]) & keep) | (uint32_t)j);
+        b2[h] = __builtin_amdgcn_fmed3f(b1[h], b2[h], ta);
+        b1[h] = min_raw(b1[h], ta);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      int order = (int)(__float_as_uint(b1[h]) & imask);
+      const bool amb = !(b2[h] > b1[h] + tol2[h]);
+      if (amb) {
+        // more than one candidate within the bound (or non-finite values): exact binary64 among the candidates, in
+        // index order, strict `<` -- FindClosestPointSet's rule (lowest index among the exact minima)
+        const float lim = b1[h] + tol2[h];
+        double best = INFINITY;
+        bool have = false;
+        order = 0;
+        for (int jj = 0; jj < nm; jj++) {
+          const float4 m4 = model32[jj];
+          const float sc = __builtin_fmaf(-q[h][0], m4.x, __builtin_fmaf(-q[h][1], m4.y, __builtin_fmaf(-q[h][2], m4.z, m4.w)));
+          if (sc <= lim || !(sc == sc) || !(lim == lim)) {
+            const double e0 = p[h][0] - model[3 * jj], e1 = p[h][1] - model[3 * jj + 1], e2 = p[h][2] - model[3 * jj + 2];
+            const double dd = e0 * e0 + e1 * e1 + e2 * e2;
+            if (!have || dd < best) {
+              best = dd;
+              order = jj;
+              have = true;
+            }
+          }
+        }
+      }
+      if (!live[h]) continue;
+      if (nn) nn[idx[h]] = order;
+      const double y0 = model[3 * order], y1 = model[3 * order + 1], y2 = model[3 * order + 2];
+      const double y[3] = {y0, y1, y2};
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        s[r] += p[h][r];
+        s[3 + r] += y[r];
+#pragma unroll
+        for (int c = 0; c < 3; c++) s[6 + 3 * r + c] += p[h][r] * y[c];
+      }
+      const double e0 = p[h][0] - y0, e1 = p[h][1] - y1, e2 = p[h][2] - y2;
+      s[15] += e0 * e0 + e1 * e1 + e2 * e2;
+    }
+  }
+  __shared__ double sm[TB / 64][16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    double v = wave_sum(s[k]);
+    if (lane == 0) sm[w][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    double v = sm[0][threadIdx.x];
+#pragma unroll
+    for (int k = 1; k < TB / 64; k++) v += sm[k][threadIdx.x];
+    partial[(size_t)blockIdx.x * 16 + threadIdx.x] = v;
+  }
+}
+
 // ---- Horn's unit-quaternion closed form (host and device: same code, same rounding) -----------------
 // cyclic Jacobi sweeps on a symmetric 4x4 (independent of the oracle's max-pivot variant).  Every index is a
 // compile-time constant after unrolling, so on the device A and V live in registers (dynamic indexing would put
@@ -355,12 +513,14 @@ __host__ __device__ inline void jacobi4(double (&A)[4][4], double (&V)[4][4]) {
       for (int j = i + 1; j < 4; j++) off += A[i][j] * A[i][j];
     }
     if (off <= 1e-34 * (diag + off) || off == 0.0) break;
+    // three rounds of two rotations in DISJOINT planes: the angle of the second reads nothing the first one writes, so
+    // the two chains of divisions and square roots overlap in the single lane that runs this
     jrot<0, 1>(A, V);
+    jrot<2, 3>(A, V);
     jrot<0, 2>(A, V);
+    jrot<1, 3>(A, V);
     jrot<0, 3>(A, V);
     jrot<1, 2>(A, V);
-    jrot<1, 3>(A, V);
-    jrot<2, 3>(A, V);
   }
 }
 
@@ -410,49 +570,48 @@ __host__ __device__ inline bool horn(const double s[16], long long nd, double R1
   return true;
 }
 
-// fixed-order reduction of the partial rows (thread t adds rows t, t+256, ... in order, then a fixed shuffle/LDS
-// tree), then thread 0 advances the ICP state by one round
-__global__ __launch_bounds__(ITPB) void k_icp_step(const double* __restrict__ partial, int nb, IcpState* __restrict__ st,
-                                                  long long nd, double tol, int stop_rule, int max_iter, int mode) {
-  if (st->done) return;
+// What follows the pass: fixed-order reduction of the partial rows (thread t adds rows t, t+TB, ... in order, then a
+// fixed shuffle/LDS tree: bitwise reproducible, no float atomics), then thread 0 advances the ICP state by one round.
+// (Running this in the pass's last workgroup -- ticket + release fence per workgroup -- was built and measured at
+// 1 M x 100: 74 us per round against 51 us for the two launches; the Horn solve's registers also halve the pass's
+// occupancy.  It stays a launch of its own.)
+template <int TB>
+__device__ __forceinline__ void icp_step_body(const double* __restrict__ partial, int nb, IcpState* __restrict__ st,
+                                              const StepArgs& a) {
   double s[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) s[k] = 0.0;
-  for (int b = threadIdx.x; b < nb; b += ITPB) {
-    const double2* row = reinterpret_cast<const double2*>(partial + (size_t)b * 16);
+  for (int b = threadIdx.x; b < nb; b += TB) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      double2 v = row[k];
-      s[2 * k] += v.x;
-      s[2 * k + 1] += v.y;
-    }
+    for (int k = 0; k < 16; k++)
+      s[k] += partial[(size_t)b * 16 + k];
   }
-  __shared__ double sm[ITPB / 64][16];
+  __shared__ double sm2[TB / 64][16];
   __shared__ double tot[16];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < 16; k++) {
     double v = wave_sum(s[k]);
-    if (lane == 0) sm[w][k] = v;
+    if (lane == 0) sm2[w][k] = v;
   }
   __syncthreads();
   if (threadIdx.x < 16) {
-    double v = sm[0][threadIdx.x];
+    double v = sm2[0][threadIdx.x];
 #pragma unroll
-    for (int k = 1; k < ITPB / 64; k++) v += sm[k][threadIdx.x];
+    for (int k = 1; k < TB / 64; k++) v += sm2[k][threadIdx.x];
     tot[threadIdx.x] = v;
     st->sums[threadIdx.x] = v;
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
-  if (mode == MODE_SUMS_ONLY) {
+  if (a.mode == MODE_SUMS_ONLY) {
     st->done = 1;
     return;
   }
   double S[16];
   for (int k = 0; k < 16; k++) S[k] = tot[k];
   double R1[9], T1[3];
-  const bool ok = horn(S, nd, R1, T1);
+  const bool ok = horn(S, a.nd, R1, T1);
   const double pre_d = st->d;
   const double d = S[15];
   st->pre_d = pre_d;
@@ -460,16 +619,16 @@ __global__ __launch_bounds__(ITPB) void k_icp_step(const double* __restrict__ pa
   const int round = st->round + 1;
   st->round = round;
   bool go;
-  if (mode == MODE_VTK) go = true;  // fixed number of rounds, mean-distance check off (FrmMain.cs:855-858)
-  else if (stop_rule == VCP_STOP_RMSE) go = sqrt(d / (double)nd) >= tol;
-  else go = fabs(d - pre_d) >= tol;  // BaseClass/ICP.cs:149,180
+  if (a.mode == MODE_VTK) go = true;  // fixed number of rounds, mean-distance check off (FrmMain.cs:855-858)
+  else if (a.stop_rule == VCP_STOP_RMSE) go = sqrt(d / (double)a.nd) >= a.tol;
+  else go = fabs(d - pre_d) >= a.tol;  // BaseClass/ICP.cs:149,180
   if (go) {
     if (!ok) {
       st->failed = 1;
       st->done = 1;
       return;
     }
-    if (mode == MODE_REFERENCE && round == 1) {  // :151-162 the first result overwrites R, T
+    if (a.mode == MODE_REFERENCE && round == 1) {  // :151-162 the first result overwrites R, T
       for (int k = 0; k < 9; k++) st->R[k] = R1[k];
       for (int k = 0; k < 3; k++) st->T[k] = T1[k];
     } else {  // :163-177  R <- R1 R, T <- R1 T + T1
@@ -489,7 +648,13 @@ __global__ __launch_bounds__(ITPB) void k_icp_step(const double* __restrict__ pa
       for (int k = 0; k < 3; k++) st->T[k] = tT[k];
     }
   }
-  if (!go || round >= max_iter) st->done = 1;
+  if (!go || round >= a.max_iter) st->done = 1;
+}
+
+__global__ __launch_bounds__(ITPB) void k_icp_step(const double* __restrict__ partial, int nb, IcpState* __restrict__ st,
+                                                  StepArgs a) {
+  if (st->done) return;
+  icp_step_body<ITPB>(partial, nb, st, a);
 }
 
 void identity(IcpState& s) {
@@ -515,11 +680,18 @@ int icp_run(vcp_ctx* ctx, const double* d_model, int64_t nm, const double* d_dat
   const bool tiled = nm > 512 && !grid;
   const bool small = grid ? nd * nng::NNG <= (int64_t)64 * ICP_MAX_BLOCKS : small0;
   const int tb = small ? 64 : ITPB;
-  const int nb = (int)vcp_blocks(grid ? nd * nng::NNG : nd, tb, ICP_MAX_BLOCKS);
+  const bool pairs = !grid && !tiled;  // scalar-cache models: two data points per lane (k_icp_pass_small)
+  const int nb = (int)vcp_blocks(grid ? nd * nng::NNG : pairs ? (nd + 1) / 2 : nd, tb, ICP_MAX_BLOCKS);
+  int ib = 1;
+  while ((1 << ib) < (int)nm) ib++;
+  const uint32_t imask = (1u << ib) - 1u;
+  double tolk = 1.0;  // smallest power of two >= (54 + 9 * 2^ib) * 2^-24
+  while (tolk * 0.5 >= (54.0 + 9.0 * (double)(1u << ib)) / 16777216.0) tolk *= 0.5;
   VCP_TRY(vcp_ensure(ctx, ctx->b_icp_part, (size_t)ICP_MAX_BLOCKS * 16 * sizeof(double) + sizeof(IcpState) + 256));
   VCP_TRY(vcp_ensure(ctx, ctx->b_aux0, (size_t)nm * sizeof(float4) + 64));
   double* part = ctx->b_icp_part.as<double>();
   IcpState* d_st = reinterpret_cast<IcpState*>(part + (size_t)ICP_MAX_BLOCKS * 16);
+  const StepArgs sa{(long long)nd, tol, stop_rule, max_iter, mode};
   float4* model32 = ctx->b_aux0.as<float4>();
   IcpState* h_st = reinterpret_cast<IcpState*>(ctx->pinned);
   *h_st = init;
@@ -537,12 +709,15 @@ int icp_run(vcp_ctx* ctx, const double* d_model, int64_t nm, const double* d_dat
       if (small && grid) VCP_PASS(64, 2);
       else if (grid) VCP_PASS(ITPB, 2);
       else if (small && tiled) VCP_PASS(64, 1);
-      else if (small) VCP_PASS(64, 0);
       else if (tiled) VCP_PASS(ITPB, 1);
-      else VCP_PASS(ITPB, 0);
+      else if (small)
+        hipLaunchKernelGGL(k_icp_pass_small<64>, dim3(nb), dim3(64), 0, st, d_model, model32, (int)nm, d_data, nd, d_st, part,
+                           d_nn, imask, tolk);
+      else
+        hipLaunchKernelGGL(k_icp_pass_small<ITPB>, dim3(nb), dim3(ITPB), 0, st, d_model, model32, (int)nm, d_data, nd, d_st,
+                           part, d_nn, imask, tolk);
 #undef VCP_PASS
-      hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(ITPB), 0, st, part, nb, d_st, (long long)nd, tol, stop_rule, max_iter,
-                         mode);
+      hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(ITPB), 0, st, part, nb, d_st, sa);
     }
     launched += batch;
     VCP_HIP(ctx, hipGetLastError());

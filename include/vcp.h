@@ -150,7 +150,8 @@ int vcp_dbscan_blocks_keyed(vcp_ctx* ctx, const double* key_xy, const double* mo
  *            (cf starts at 0 in every block, FrmMain.cs:2785) into d_local[pos_lo..pos_hi)
  *   -- the caller all-gathers the slices of d_local (RCCL) and sums the per-rank evals --
  *   finish   CompleteWork3 on the full d_local [m]; d_* outputs are device pointers
- * The state lives in the context until the next begin. */
+ * The state lives in the context until the next begin.  The _dev forms of begin read d_motor (and d_key_xy) in
+ * place: the caller keeps those arrays valid and unchanged until the finish stage has returned. */
 int vcp_blocks_begin(vcp_ctx* ctx, const double* motor, int64_t n, double eps, int min_pts,
                      int pts_in_cell, int small_max, int32_t* rows, int32_t* cols, int64_t* nblocks,
                      int64_t* m);

@@ -30,7 +30,8 @@ struct BlocksState {
   double eps = 0;
   int min_pts = 0, small_max = 3, take = 0;
   double x_Min = 0, x_Max = 0, y_Min = 0, y_Max = 0, cell_x = 0, cell_y = 0;
-  DevBuf motor, pkey, orand, raw, rankpos, blockof, bl, motor_bm, blockstart, gtwice, gnclus, tmp0, tmp1, tmp2, tmp3, sorttmp,
+  const double* motor_ptr = nullptr;  // the cloud on the device: our upload (host entry points) or the caller's array
+  DevBuf motor, pkey, orand, raw, blockof, bl, motor_bm, blockstart, gtwice, gnclus, tmp0, tmp1, tmp2, tmp3, sorttmp,
       blk_t, csize, cstart, kb, zb, keep, order, newlab, zflag, zlist, zcoords, zlab, misc;
   std::vector<uint32_t> h_blockstart;
   bool ready = false;
@@ -235,11 +236,6 @@ __global__ __launch_bounds__(BT) void k_sortkey(const double* __restrict__ motor
   }
 }
 
-__global__ __launch_bounds__(BT) void k_inverse(const uint32_t* __restrict__ perm, int64_t n, uint32_t* __restrict__ inv) {
-  int64_t t = (int64_t)blockIdx.x * BT + threadIdx.x;
-  if (t < n) inv[perm[t]] = (uint32_t)t;
-}
-
 struct PartP {
   double x_Min, x_Max, y_Min, y_Max, cell_x, cell_y;
   int rows, cols, take;
@@ -264,15 +260,20 @@ __device__ __forceinline__ int find_axis(double v, double vmin, double vmax, dou
   return -1;
 }
 
-__global__ __launch_bounds__(BT) void k_block_of(const double* __restrict__ motor, int64_t n, PartP P,
-                                                const uint32_t* __restrict__ rankpos, int32_t* __restrict__ blockof) {
+// The first block is rawData.Take(ptsInCell) of the list sorted by d = max(x - x_Min, y - y_Min) (stable: ties keep the
+// input order), i.e. exactly the points whose (d, index) is <= that of the take-th element (key_T, idx_T): no rank array.
+__global__ __launch_bounds__(BT) void k_block_of(const double* __restrict__ motor, int64_t n, PartP P, uint64_t key_T,
+                                                uint32_t idx_T, int32_t* __restrict__ blockof) {
   int64_t i = (int64_t)blockIdx.x * BT + threadIdx.x;
   if (i >= n) return;
   int32_t b = -1;
-  if (rankpos[i] < (uint32_t)P.take) {
+  const double2 v = *reinterpret_cast<const double2*>(motor + 2 * i);
+  const double da = v.x - P.x_Min, db = v.y - P.y_Min;
+  const double d = da > db ? da : db;
+  const uint64_t k = (uint64_t)__double_as_longlong(d + 0.0);  // k_sortkey's key
+  if (k < key_T || (k == key_T && (uint32_t)i <= idx_T)) {
     b = 0;  // cells[0] = rawData.Take(ptsInCell), FrmMain.cs:1254,1260
   } else {
-    double2 v = *reinterpret_cast<const double2*>(motor + 2 * i);
     int q = find_axis(v.x, P.x_Min, P.x_Max, P.cell_x, P.cols);
     int p = find_axis(v.y, P.y_Min, P.y_Max, P.cell_y, P.rows);
     if (p >= 0 && q >= 0) {
@@ -451,10 +452,12 @@ __global__ __launch_bounds__(BT) void k_compact(const uint32_t* __restrict__ zfl
     merge_order[u - zr] = (int64_t)i;
   }
 }
+// every label by original index: block-major positions < m carry the renumbered id (0 = noise / demoted), the rest of
+// the list (points in no block) 0 -- the whole array is written, nothing has to be cleared first
 __global__ __launch_bounds__(BT) void k_final_labels(const int32_t* __restrict__ newlab, const uint32_t* __restrict__ bl,
-                                                    int64_t m, int32_t* __restrict__ labels) {
+                                                    int64_t m, int64_t n, int32_t* __restrict__ labels) {
   int64_t t = (int64_t)blockIdx.x * BT + threadIdx.x;
-  if (t < m && newlab[t] != 0) labels[bl[t]] = newlab[t];
+  if (t < n) labels[bl[t]] = t < m ? newlab[t] : 0;
 }
 __global__ __launch_bounds__(BT) void k_scatter_zlab(const int32_t* __restrict__ zlab, const uint32_t* __restrict__ zlist,
                                                     uint32_t Z, int32_t* __restrict__ labels) {
@@ -484,13 +487,20 @@ int blocks_begin(vcp_ctx* ctx, const double* d_motor_in, bool from_host, const d
   s->eps = eps;
   s->min_pts = min_pts;
   s->small_max = small_max;
-  VCP_TRY(ens(ctx, s->motor, (size_t)n * 16));
-  if (from_host) VCP_HIP(ctx, hipMemcpyAsync(s->motor.p, h_motor, (size_t)n * 16, hipMemcpyHostToDevice, st));
-  else VCP_HIP(ctx, hipMemcpyAsync(s->motor.p, d_motor_in, (size_t)n * 16, hipMemcpyDeviceToDevice, st));
-  const double* motor_own = s->motor.as<double>();
+  // host entry points upload into the state's own buffers; device entry points are read in place: the caller keeps
+  // d_motor (and d_key_xy) valid and unchanged until the finish stage has returned (include/vcp.h)
+  const double* motor_own = d_motor_in;
+  if (from_host) {
+    VCP_TRY(ens(ctx, s->motor, (size_t)n * 16));
+    VCP_HIP(ctx, hipMemcpyAsync(s->motor.p, h_motor, (size_t)n * 16, hipMemcpyHostToDevice, st));
+    motor_own = s->motor.as<double>();
+  }
+  s->motor_ptr = motor_own;
   if (key_in) {
-    VCP_TRY(ens(ctx, s->pkey, (size_t)n * 16));
-    VCP_HIP(ctx, hipMemcpyAsync(s->pkey.p, key_in, (size_t)n * 16, from_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
+    if (from_host) {
+      VCP_TRY(ens(ctx, s->pkey, (size_t)n * 16));
+      VCP_HIP(ctx, hipMemcpyAsync(s->pkey.p, key_in, (size_t)n * 16, hipMemcpyHostToDevice, st));
+    }
     // a non-finite motor coordinate would reach DBImproved only; the partition's own check below covers the keys
     const int rbm = (int)vcp_blocks(n, BT, 1024);
     VCP_TRY(ens(ctx, s->misc, (size_t)(rbm * 5 + 64) * 8));
@@ -503,7 +513,7 @@ int blocks_begin(vcp_ctx* ctx, const double* d_motor_in, bool from_host, const d
     VCP_HIP(ctx, hipStreamSynchronize(st));
     if (hm[4] != 0.0) return vcp_fail(ctx, VCP_ERR_ARG, "non-finite motor coordinates");
   }
-  const double* motor = key_in ? s->pkey.as<double>() : motor_own;  // what the partition reads from here on
+  const double* motor = key_in ? (from_host ? s->pkey.as<double>() : key_in) : motor_own;  // what the partition reads
   // bounds (FrmMain.cs:1224-1227) and the finiteness check
   const int rb = (int)vcp_blocks(n, BT, 1024);
   VCP_TRY(ens(ctx, s->misc, (size_t)(rb * 5 + 64) * 8));
@@ -524,7 +534,6 @@ int blocks_begin(vcp_ctx* ctx, const double* d_motor_in, bool from_host, const d
   VCP_TRY(ens(ctx, s->tmp1, (size_t)n * 8));
   VCP_TRY(ens(ctx, s->tmp2, (size_t)n * 4));
   VCP_TRY(ens(ctx, s->raw, (size_t)n * 4));
-  VCP_TRY(ens(ctx, s->rankpos, (size_t)n * 4));
   VCP_TRY(ens(ctx, s->orand, 64 * 8));
   unsigned long long* orand = s->orand.as<unsigned long long>();
   VCP_HIP(ctx, hipMemsetAsync(orand, 0, 32 * 8, st));
@@ -558,12 +567,17 @@ int blocks_begin(vcp_ctx* ctx, const double* d_motor_in, bool from_host, const d
     VCP_HIP(ctx, rocprim::radix_sort_pairs(s->sorttmp.p, tb, s->tmp0.as<uint64_t>(), s->tmp1.as<uint64_t>(),
                                            s->tmp2.as<uint32_t>(), s->raw.as<uint32_t>(), (size_t)n, bit_lo, bit_hi, st));
   }
-  hipLaunchKernelGGL(k_inverse, dim3(nblk(n)), dim3(BT), 0, st, s->raw.as<uint32_t>(), n, s->rankpos.as<uint32_t>());
-  // first block -> block size (FrmMain.cs:1253-1258)
+  // first block -> block size (FrmMain.cs:1253-1258); its last element's (key, index) tells every point whether it is in
   s->take = (int)std::min<int64_t>(pts_in_cell, n);
   hipLaunchKernelGGL(k_minmax2, dim3(1), dim3(BT), 0, st, motor, s->raw.as<uint32_t>(), (int64_t)s->take, out);
   VCP_HIP(ctx, hipMemcpyAsync(h, out, 5 * 8, hipMemcpyDeviceToHost, st));
+  uint64_t* h_keyT = reinterpret_cast<uint64_t*>(ctx->pinned) + 16;
+  uint32_t* h_idxT = reinterpret_cast<uint32_t*>(h_keyT + 1);
+  VCP_HIP(ctx, hipMemcpyAsync(h_keyT, s->tmp1.as<uint64_t>() + (s->take - 1), 8, hipMemcpyDeviceToHost, st));
+  VCP_HIP(ctx, hipMemcpyAsync(h_idxT, s->raw.as<uint32_t>() + (s->take - 1), 4, hipMemcpyDeviceToHost, st));
   VCP_HIP(ctx, hipStreamSynchronize(st));
+  const uint64_t key_T = *h_keyT;
+  const uint32_t idx_T = *h_idxT;
   s->cell_x = h[1] - s->x_Min;
   s->cell_y = h[3] - s->y_Min;
   const double fr = (s->y_Max - s->y_Min) / s->cell_y, fc = (s->x_Max - s->x_Min) / s->cell_x;
@@ -579,8 +593,7 @@ int blocks_begin(vcp_ctx* ctx, const double* d_motor_in, bool from_host, const d
   // block of every point (FrmMain.cs:1259-1285, Tools.cs:510-513)
   PartP P{s->x_Min, s->x_Max, s->y_Min, s->y_Max, s->cell_x, s->cell_y, s->rows, s->cols, s->take};
   VCP_TRY(ens(ctx, s->blockof, (size_t)n * 4));
-  hipLaunchKernelGGL(k_block_of, dim3(nblk(n)), dim3(BT), 0, st, motor, n, P, s->rankpos.as<uint32_t>(),
-                     s->blockof.as<int32_t>());
+  hipLaunchKernelGGL(k_block_of, dim3(nblk(n)), dim3(BT), 0, st, motor, n, P, key_T, idx_T, s->blockof.as<int32_t>());
   // block-major list: stable sort of the list order by block id; dropped points go last
   const int64_t nb1 = s->nblocks + 1;
   VCP_TRY(ens(ctx, s->blockstart, (size_t)(nb1 + 1) * 4));
@@ -702,7 +715,7 @@ int blocks_finish(vcp_ctx* ctx, const int32_t* d_local, int64_t evals_blocks, in
   // zero list (FrmMain.cs:1510-1515) and merge order
   VCP_TRY(ens(ctx, s->zflag, (size_t)(m + 2) * 4));
   uint32_t* zflag = s->zflag.as<uint32_t>();
-  VCP_HIP(ctx, hipMemsetAsync(zflag, 0, (size_t)(m + 2) * 4, st));
+  VCP_HIP(ctx, hipMemsetAsync(zflag + m, 0, 8, st));  // k_zero_flag writes [0, m); the scan reads one entry more
   if (m > 0) hipLaunchKernelGGL(k_zero_flag, dim3(nblk(m)), dim3(BT), 0, st, newlab, order, m, zflag);
   VCP_TRY(vcp_exclusive_scan_u32(ctx, zflag, zflag, m + 1, dmisc + 3));
   VCP_HIP(ctx, hipMemcpyAsync(hp, dmisc, 16, hipMemcpyDeviceToHost, st));
@@ -716,10 +729,9 @@ int blocks_finish(vcp_ctx* ctx, const int32_t* d_local, int64_t evals_blocks, in
   VCP_TRY(ens(ctx, s->zlab, (size_t)(Z + 1) * 4));
   if (m > 0)
     hipLaunchKernelGGL(k_compact, dim3(nblk(m)), dim3(BT), 0, st, zflag, newlab, order, s->bl.as<uint32_t>(),
-                       s->motor.as<double>(), m, Z, s->zlist.as<uint32_t>(), s->zcoords.as<double>(), d_merge_order);
+                       s->motor_ptr, m, Z, s->zlist.as<uint32_t>(), s->zcoords.as<double>(), d_merge_order);
   // labels by original index: kept clusters now, the noise pass result on top
-  VCP_HIP(ctx, hipMemsetAsync(d_labels, 0, (size_t)n * 4, st));
-  if (m > 0) hipLaunchKernelGGL(k_final_labels, dim3(nblk(m)), dim3(BT), 0, st, newlab, s->bl.as<uint32_t>(), m, d_labels);
+  hipLaunchKernelGGL(k_final_labels, dim3(nblk(n)), dim3(BT), 0, st, newlab, s->bl.as<uint32_t>(), m, n, d_labels);
   VCP_HIP(ctx, hipGetLastError());
   // FrmMain.cs:1507-1516: one DBImproved over all noise, cf preset to the kept-cluster count
   int32_t cf = (int32_t)kept;
@@ -746,7 +758,7 @@ extern "C" {
 void vcp_blocks_state_free(vcp_ctx* ctx) {
   if (!ctx || !ctx->blocks) return;
   BlocksState* s = ctx->blocks;
-  DevBuf* all[] = {&s->motor, &s->pkey, &s->orand, &s->raw, &s->rankpos, &s->blockof, &s->bl, &s->motor_bm, &s->blockstart,
+  DevBuf* all[] = {&s->motor, &s->pkey, &s->orand, &s->raw, &s->blockof, &s->bl, &s->motor_bm, &s->blockstart,
                    &s->gtwice, &s->gnclus, &s->tmp0, &s->tmp1, &s->tmp2, &s->tmp3, &s->sorttmp, &s->blk_t, &s->csize,
                    &s->cstart, &s->kb, &s->zb, &s->keep, &s->order, &s->newlab, &s->zflag, &s->zlist, &s->zcoords,
                    &s->zlab, &s->misc};

@@ -281,12 +281,14 @@ __global__ __launch_bounds__(FT) void k_part_fine(const Rec* __restrict__ rec, u
 }
 
 // ---- cell order -> caller order --------------------------------------------------------------------------
-// Windows of 2^OWSH list positions: 8192 x (4 + 1 + 1) bytes are assembled in LDS and stored as full lines (0.022 ms for
+// Windows of 2^OWSH list positions: the label words are assembled in LDS and stored as full lines (0.022 ms for
 // 10 M points, against 0.15 ms for the same stores made straight from the lanes -- tools/micro/part_bench.hip).
-constexpr int OWSH = 13;
+// OWSH (log2 of the window) is chosen per call: 15 from 8 M points (longer runs per window in the scatter pass: 0.086 ms
+// against 0.134 ms at 13 for 10 M points), 14 / 13 below, so that smaller clouds still fill the CUs with windows.
 constexpr int OT = 1024, OPT = 16;  // scatter pass: OT * OPT positions per workgroup (longer runs per window)
 constexpr int OWT = 512;           // write pass: one workgroup per window
 
+template <int OWSH>
 __global__ __launch_bounds__(OT) void k_out_scatter(const uint32_t* __restrict__ sord, const uint32_t* __restrict__ labk,
                                                    int64_t n, uint32_t OB, uint32_t* __restrict__ gcur,
                                                    uint2* __restrict__ rec) {
@@ -320,44 +322,51 @@ __global__ __launch_bounds__(OT) void k_out_scatter(const uint32_t* __restrict__
   }
 }
 
+template <int OWSH>
 __global__ __launch_bounds__(OWT) void k_out_write(const uint2* __restrict__ rec, int64_t n, bool have_in_classed,
                                                   int32_t cf_in, int32_t* __restrict__ labels,
                                                   uint8_t* __restrict__ is_core, uint8_t* __restrict__ is_classed,
                                                   unsigned long long* __restrict__ counters, uint32_t* __restrict__ gcur) {
-  __shared__ int32_t sl[1 << OWSH];
+  extern __shared__ __attribute__((aligned(16))) uint32_t sw[];  // [2^OWSH] label words by list position
   if (threadIdx.x == 0) gcur[blockIdx.x] = 0u;  // the window cursors are left at zero for the next call
-  __shared__ __attribute__((aligned(16))) uint8_t sc[1 << OWSH], sk[1 << OWSH];
   const int64_t lo = (int64_t)blockIdx.x << OWSH;
   const uint32_t cnt = (uint32_t)min((int64_t)1 << OWSH, n - lo);  // every list position appears exactly once
   unsigned unclassed = 0;
   for (uint32_t j = threadIdx.x; j < cnt; j += OWT) {
     const uint2 v = rec[lo + j];
-    const uint32_t o = v.x - (uint32_t)lo, k1 = v.y >> 2;
-    const bool core = v.y & 1u, classed = v.y & 2u;
-    const int32_t lab = k1 ? cf_in + (int32_t)k1 : 0;
-    sl[o] = lab;
-    sc[o] = (core && !classed) ? 1 : 0;
-    sk[o] = (classed || lab != 0) ? 1 : 0;
-    if (!classed) unclassed++;
+    sw[v.x - (uint32_t)lo] = v.y;  // (1 + seed rank) << 2 | core | classed << 1
+    if (!(v.y & 2u)) unclassed++;
   }
   __syncthreads();
-  if (have_in_classed) {  // labels are in/out: a point this call does not label keeps its id
-    for (uint32_t j = threadIdx.x; j < cnt; j += OWT)
-      if (sl[j] != 0) labels[lo + j] = sl[j];
-  } else {
-    for (uint32_t j = threadIdx.x; j < cnt; j += OWT) labels[lo + j] = sl[j];
+  // one word per position in LDS (64 KB for 2^14 positions: two workgroups per CU); labels and the two byte arrays are
+  // derived from it on the way out, 4 positions per lane where the window is whole (lo is a multiple of 2^OWSH)
+  auto lab_of = [&](uint32_t w) { return (w >> 2) ? cf_in + (int32_t)(w >> 2) : 0; };
+  auto core_of = [](uint32_t w) { return (uint32_t)((w & 3u) == 1u); };                // core and not classed on entry
+  auto cls_of = [](uint32_t w) { return (uint32_t)((w & 2u) != 0u || (w >> 2) != 0u); };  // classed, or labelled now
+  const bool vec = (((uintptr_t)labels & 15u) | ((uintptr_t)is_core & 3u) | ((uintptr_t)is_classed & 3u)) == 0;  // caller's pointers
+  const uint32_t c4 = vec ? cnt >> 2 : 0u;
+  for (uint32_t j = threadIdx.x; j < c4; j += OWT) {
+    const uint4 w = reinterpret_cast<const uint4*>(sw)[j];
+    const int4 l = make_int4(lab_of(w.x), lab_of(w.y), lab_of(w.z), lab_of(w.w));
+    if (have_in_classed) {  // labels are in/out: a point this call does not label keeps its id
+      if (l.x) labels[lo + 4 * j] = l.x;
+      if (l.y) labels[lo + 4 * j + 1] = l.y;
+      if (l.z) labels[lo + 4 * j + 2] = l.z;
+      if (l.w) labels[lo + 4 * j + 3] = l.w;
+    } else {
+      reinterpret_cast<int4*>(labels + lo)[j] = l;
+    }
+    if (is_core)
+      reinterpret_cast<uint32_t*>(is_core + lo)[j] = core_of(w.x) | core_of(w.y) << 8 | core_of(w.z) << 16 | core_of(w.w) << 24;
+    if (is_classed)
+      reinterpret_cast<uint32_t*>(is_classed + lo)[j] = cls_of(w.x) | cls_of(w.y) << 8 | cls_of(w.z) << 16 | cls_of(w.w) << 24;
   }
-  // the byte arrays: 4 entries per lane where the window is whole (lo is a multiple of 2^OWSH)
-  const uint32_t c4 = cnt >> 2;
-  if (is_core) {
-    for (uint32_t j = threadIdx.x; j < c4; j += OWT)
-      reinterpret_cast<uint32_t*>(is_core + lo)[j] = reinterpret_cast<const uint32_t*>(sc)[j];
-    for (uint32_t j = (c4 << 2) + threadIdx.x; j < cnt; j += OWT) is_core[lo + j] = sc[j];
-  }
-  if (is_classed) {
-    for (uint32_t j = threadIdx.x; j < c4; j += OWT)
-      reinterpret_cast<uint32_t*>(is_classed + lo)[j] = reinterpret_cast<const uint32_t*>(sk)[j];
-    for (uint32_t j = (c4 << 2) + threadIdx.x; j < cnt; j += OWT) is_classed[lo + j] = sk[j];
+  for (uint32_t j = (c4 << 2) + threadIdx.x; j < cnt; j += OWT) {
+    const uint32_t w = sw[j];
+    const int32_t l = lab_of(w);
+    if (!have_in_classed || l) labels[lo + j] = l;
+    if (is_core) is_core[lo + j] = (uint8_t)core_of(w);
+    if (is_classed) is_classed[lo + j] = (uint8_t)cls_of(w);
   }
   if (have_in_classed) {  // one atomic per workgroup, spread over 32 slots (a single hot word serialises)
     __shared__ unsigned wc[OWT / 64];
@@ -433,10 +442,10 @@ int vcp_grid_build_partition(vcp_ctx* ctx, const GridBuildArgs& a) {
   return grouped ? build<2, true>(ctx, a) : build<2, false>(ctx, a);
 }
 
-int vcp_grid_output_partition(vcp_ctx* ctx, const GridOutputArgs& a) {
+template <int OWSH>
+static int output_partition(vcp_ctx* ctx, const GridOutputArgs& a) {
   hipStream_t st = ctx->stream;
   const uint32_t OB = (uint32_t)((a.n + (1 << OWSH) - 1) >> OWSH);
-  if (OB > 16384) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "more than 2^27 points: use the gather output");
   // window cursors: zero between calls (k_out_write leaves them so), cleared here only when the array is new
   const void* before = ctx->b_outcur.p;
   const size_t before_cap = ctx->b_outcur.cap;
@@ -447,11 +456,19 @@ int vcp_grid_output_partition(vcp_ctx* ctx, const GridOutputArgs& a) {
   uint32_t* gcur = ctx->b_outcur.as<uint32_t>();
   uint2* rec = ctx->b_rec.as<uint2>();
   vcp_phase(ctx, "out_scatter");
-  hipLaunchKernelGGL(k_out_scatter, dim3(vcp_blocks(a.n, OT * OPT)), dim3(OT), (size_t)OB * 4, st, a.sord, a.labk, a.n, OB,
-                     gcur, rec);
+  hipLaunchKernelGGL(k_out_scatter<OWSH>, dim3(vcp_blocks(a.n, OT * OPT)), dim3(OT), (size_t)OB * 4, st, a.sord, a.labk, a.n,
+                     OB, gcur, rec);
   vcp_phase(ctx, "out_write");
-  hipLaunchKernelGGL(k_out_write, dim3(OB), dim3(OWT), 0, st, rec, a.n, a.have_in_classed, a.cf_in, a.labels, a.is_core,
-                     a.is_classed, a.counters, gcur);
+  VCP_TRY(allow_lds(ctx, k_out_write<OWSH>, (size_t)4 << OWSH));
+  hipLaunchKernelGGL(k_out_write<OWSH>, dim3(OB), dim3(OWT), (size_t)4 << OWSH, st, rec, a.n, a.have_in_classed, a.cf_in,
+                     a.labels, a.is_core, a.is_classed, a.counters, gcur);
   VCP_HIP(ctx, hipGetLastError());
   return VCP_OK;
+}
+
+int vcp_grid_output_partition(vcp_ctx* ctx, const GridOutputArgs& a) {
+  if (a.n > ((int64_t)1 << 27)) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "more than 2^27 points: use the gather output");
+  if (a.n >= ((int64_t)1 << 23)) return output_partition<15>(ctx, a);
+  if (a.n >= ((int64_t)1 << 22)) return output_partition<14>(ctx, a);
+  return output_partition<13>(ctx, a);
 }

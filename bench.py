@@ -42,16 +42,16 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 ALGO_BYTES_PER_POINT = {
     "bounds": 16,               # R coords
     "part_hist": 16,            # R coords (the chunk x bucket counts are ~0.4 B per point)
-    "part_scatter": 16 + 32,    # R coords, W one 32-byte record (x, y, index)
-    # R records (the second read of a bucket is served by L2); W sorted 16 + binary32 copy 8 + list position 4 +
+    "part_scatter": 16 + 16,    # R coords, W one 16-byte record (binary32 x, y relative to the grid origin, index, cell)
+    # R records (the second read of a bucket is served by L2); W binary32 coordinates 8 + list position 4 +
     # 4 B per cell of the cell table (5 cells per point on this cloud)
-    "part_fine": 32 + 16 + 8 + 4 + 20,
-    # R own point 16 + 8, staged binary32 rows ~8, flags 1; W flags 1, parent 4, minord 4, neighbour lists (3.6 entries
-    # per point on this cloud) 14.5 + offset 2; work-list fill R 1 + W 2.4
-    "core_count": 54,
+    "part_fine": 16 + 8 + 4 + 20,
+    # R own point 8, staged binary32 rows ~8; W flags 1, parent 4, minord 4, neighbour lists (3.6 entries
+    # per point on this cloud) 14.5 + offset 2; work-list fill R 1 + W 2.4 (+ 0.1 clearing the seed bitmap)
+    "core_count": 45,
     # list links R 1 + 9 per expanding point (a quarter of the points) ..., candidate parent words (cache-served, once
-    # per point), coordinates of the expanding points
-    "union": 25,
+    # per point), binary32 coordinates of the expanding points
+    "union": 21,
     "flatten_number": 10,       # work-list kernels over the expanding points + seed bitmap
     # rank extension R 5 + W 8 for every point; list walk (flags, ~3 list words, ~3 rank words, sord, labk) for the third
     # of the points that are border candidates

@@ -127,3 +127,26 @@ def test_keyed_partition_getClusterFromList(vcp_ctx, oracle):
     fin = vcp_ctx.blocks_finish_dev(local.data_ptr(), ev, lab.data_ptr())
     assert np.array_equal(lab.cpu().numpy(), o["labels"]) and fin["cluster_amount"] == o["cluster_amount"]
     assert fin["evals"] == o["evals"]
+
+
+def test_final_order_counting_sort_equals_library_sort(vcp_ctx, oracle):
+    """CompleteWork3's order inside a block (stable by local id) comes from a per-block counting sort; the library
+    radix-sort form stays for blocks with more ids than its table holds.  Both against the oracle and each other, on
+    blocks of a few points (many empty ones) and of thousands (ptsInCell 5000: dozens of clusters per block)."""
+    import os
+    rng = np.random.default_rng(55)
+    for n, eps, mp, pic in ((30_000, 0.1, 4, 20), (300_000, 0.07, 7, 5000), (200_000, 0.1, 10, 200)):
+        d = synth.config_cloud(n, seed=int(rng.integers(1, 99)))
+        o = oracle.block_pipeline(d["motor"], eps, mp, pic, 3)
+        got = []
+        for force in (False, True):
+            if force:
+                os.environ["VCP_BLOCKS_ORDER_SORT"] = "1"
+            try:
+                got.append(vcp_ctx.dbscan_blocks(d["motor"], eps, mp, pic, 3))
+            finally:
+                os.environ.pop("VCP_BLOCKS_ORDER_SORT", None)
+        for g in got:
+            assert np.array_equal(g["labels"], o["labels"])
+            assert np.array_equal(g["order"], o["order"])
+            assert g["kept"] == o["kept"] and g["cluster_amount"] == o["cluster_amount"] and g["evals"] == o["evals"]

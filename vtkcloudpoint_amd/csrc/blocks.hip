@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -34,6 +35,8 @@ struct BlocksState {
   DevBuf motor, pkey, orand, raw, blockof, bl, motor_bm, blockstart, gtwice, gnclus, tmp0, tmp1, tmp2, tmp3, sorttmp,
       blk_t, csize, cstart, kb, zb, keep, order, newlab, zflag, zlist, zcoords, zlab, misc;
   std::vector<uint32_t> h_blockstart;
+  DevBuf biglist;     // blocks of more than BIG_BLOCK points (k_block_order<16>), found on the host at begin
+  uint32_t nbig = 0;
   bool ready = false;
 };
 
@@ -369,6 +372,89 @@ __global__ __launch_bounds__(BT) void k_cluster_sizes(const int32_t* __restrict_
     }
   }
 }
+// Final order inside a block = stable by local id (noise, id 0, first): a counting sort per block.  Ids are counted in
+// LDS, scanned, then the block's positions are placed in order -- per chunk of 64 positions the lanes that hold the same
+// id take consecutive slots (one ballot per distinct id in the chunk).  Replaces two library radix sorts over all m
+// positions (by local id, then by block) when no block has more than CS_CAP ids.
+//   NW = 1: one wave per block, four blocks per workgroup: blocks of up to BIG_BLOCK positions (a block holds
+//           ~ptsInCell points);
+//   NW = 16: one workgroup per block of the host's list of large blocks (the heart of a blob can put 10^4 points in
+//           one rectangle; a single wave walking it set the kernel time: 415 us): every wave reads the whole block but
+//           places only the ids congruent to its number, so each cursor has one owner and the order stays stable.
+constexpr uint32_t BIG_BLOCK = 1024;
+template <int NW>
+__global__ __launch_bounds__(NW == 1 ? BT : 64 * NW) void k_block_order(const int32_t* __restrict__ local,
+                                                                       const uint32_t* __restrict__ blockstart,
+                                                                       int64_t nblocks, const uint32_t* __restrict__ kb,
+                                                                       const uint32_t* __restrict__ biglist,
+                                                                       uint32_t* __restrict__ order) {
+  constexpr int NG = NW == 1 ? BT / 64 : 1;  // blocks per workgroup
+  __shared__ uint32_t cnt[NG][CS_CAP + 1];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int g = NW == 1 ? w : 0;       // which of the workgroup's blocks
+  const int me = NW == 1 ? 0 : w;      // which ids this wave places (id % NW)
+  int64_t b;
+  if (NW == 1) {
+    b = (int64_t)blockIdx.x * NG + w;
+    if (b >= nblocks) return;  // whole waves leave together; no workgroup barrier below for NW == 1
+  } else {
+    b = biglist[blockIdx.x];
+  }
+  const uint32_t s0 = blockstart[b], s1 = blockstart[b + 1];
+  if (NW == 1 && (s0 == s1 || s1 - s0 > BIG_BLOCK)) return;
+  const uint32_t K = kb[b];  // ids 0..K
+  const uint32_t nthr = 64 * NW, tid = NW == 1 ? lane : threadIdx.x;
+  for (uint32_t k = tid; k <= K; k += nthr) cnt[g][k] = 0;
+  if (NW == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+  for (uint32_t t = s0 + tid; t < s1; t += nthr) atomicAdd(&cnt[g][local[t]], 1u);
+  if (NW == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+  if (w == 0 || NW == 1) {
+    // exclusive scan of cnt[0..K] by one wave, 64 entries per trip
+    uint32_t carry = s0;
+    for (uint32_t k0 = 0; k0 <= K; k0 += 64) {
+      const uint32_t k = k0 + lane;
+      const uint32_t v = k <= K ? cnt[g][k] : 0u;
+      uint32_t inc = v;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+      }
+      if (k <= K) cnt[g][k] = carry + inc - v;  // first final position of id k
+      carry += __shfl(inc, 63, 64);
+    }
+  }
+  if (NW == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+  // NW > 1: the ids come through LDS in tiles loaded by the whole workgroup (a wave walking a large block chunk by chunk
+  // would wait for one global load per chunk: 400 dependent loads for 25 k points)
+  constexpr uint32_t TILE = NW == 1 ? 64 : 8192;
+  __shared__ uint16_t ids[NW == 1 ? 1 : TILE];
+  for (uint32_t tile0 = s0; tile0 < s1; tile0 += TILE) {
+    const uint32_t tend = min(tile0 + TILE, s1);
+    if (NW > 1) {
+      __syncthreads();  // the previous tile has been consumed
+      for (uint32_t t = tile0 + tid; t < tend; t += nthr) ids[t - tile0] = (uint16_t)local[t];  // ids <= CS_CAP
+      __syncthreads();
+    }
+    for (uint32_t t0 = tile0; t0 < tend; t0 += 64) {
+      const uint32_t t = t0 + lane;
+      const uint32_t id = t < tend ? (NW == 1 ? (uint32_t)local[t] : (uint32_t)ids[t - tile0]) : 0xFFFFFFFFu;
+      const bool mine = t < tend && (NW == 1 || id % NW == (uint32_t)me);
+      unsigned long long todo = __ballot(mine);
+      while (todo) {
+        const int first = __ffsll((long long)todo) - 1;
+        const uint32_t cur = (uint32_t)__shfl((int)id, first, 64);
+        const unsigned long long same = __ballot(mine && id == cur);
+        const uint32_t base = cnt[g][cur];
+        if (mine && id == cur) order[base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = t;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == first) cnt[g][cur] = base + (uint32_t)__popcll(same);
+        __builtin_amdgcn_wave_barrier();
+        todo &= ~same;
+      }
+    }
+  }
+}
 // keep[c] for cluster entry c = cstart[b] + k - 1 (FrmMain.cs:1479-1495): a cluster is demoted when the next
 // id shows up and clusLen <= small_max; clusLen over-counts the first cluster of a block without noise by
 // one (:1461-1465); the last cluster of a block is never checked.
@@ -617,6 +703,17 @@ int blocks_begin(vcp_ctx* ctx, const double* d_motor_in, bool from_host, const d
   VCP_HIP(ctx, hipStreamSynchronize(st));
   s->m = s->h_blockstart[(size_t)s->nblocks];
   if (m_o) *m_o = s->m;
+  {
+    std::vector<uint32_t> big;
+    for (int64_t b = 0; b < s->nblocks; b++)
+      if (s->h_blockstart[(size_t)b + 1] - s->h_blockstart[(size_t)b] > BIG_BLOCK) big.push_back((uint32_t)b);
+    s->nbig = (uint32_t)big.size();
+    if (s->nbig) {
+      VCP_TRY(ens(ctx, s->biglist, big.size() * 4));
+      VCP_HIP(ctx, hipMemcpyAsync(s->biglist.p, big.data(), big.size() * 4, hipMemcpyHostToDevice, st));
+      VCP_HIP(ctx, hipStreamSynchronize(st));  // `big` is a local buffer
+    }
+  }
   VCP_TRY(ens(ctx, s->gtwice, (size_t)nb1 * 4));
   VCP_TRY(ens(ctx, s->gnclus, (size_t)nb1 * 4));
   s->ready = true;
@@ -704,7 +801,13 @@ int blocks_finish(vcp_ctx* ctx, const int32_t* d_local, int64_t evals_blocks, in
   uint32_t* v1o = s->tmp1.as<uint32_t>();
   uint32_t* k2 = v1o + (m + 1);
   uint32_t* order = s->order.as<uint32_t>();
-  if (m > 0) {
+  const bool order_by_sort = getenv("VCP_BLOCKS_ORDER_SORT") != nullptr;  // test switch: the library-sort form
+  if (m > 0 && maxK <= (uint32_t)CS_CAP && !order_by_sort) {
+    hipLaunchKernelGGL(k_block_order<1>, dim3(nbw), dim3(BT), 0, st, d_local, blockstart, nb, kb, nullptr, order);
+    if (s->nbig)
+      hipLaunchKernelGGL(k_block_order<16>, dim3(s->nbig), dim3(1024), 0, st, d_local, blockstart, nb, kb,
+                         s->biglist.as<uint32_t>(), order);
+  } else if (m > 0) {
     hipLaunchKernelGGL(k_iota, dim3(nblk(m)), dim3(BT), 0, st, iota, m);
     VCP_HIP(ctx, hipMemcpyAsync(k1, d_local, (size_t)m * 4, hipMemcpyDeviceToDevice, st));
     VCP_TRY(sort_pairs(ctx, s, k1, k1o, iota, v1o, (size_t)m, bits_for(maxK)));
@@ -761,7 +864,7 @@ void vcp_blocks_state_free(vcp_ctx* ctx) {
   DevBuf* all[] = {&s->motor, &s->pkey, &s->orand, &s->raw, &s->blockof, &s->bl, &s->motor_bm, &s->blockstart,
                    &s->gtwice, &s->gnclus, &s->tmp0, &s->tmp1, &s->tmp2, &s->tmp3, &s->sorttmp, &s->blk_t, &s->csize,
                    &s->cstart, &s->kb, &s->zb, &s->keep, &s->order, &s->newlab, &s->zflag, &s->zlist, &s->zcoords,
-                   &s->zlab, &s->misc};
+                   &s->zlab, &s->misc, &s->biglist};
   for (DevBuf* b : all)
     if (b->p) (void)hipFree(b->p);
   delete s;

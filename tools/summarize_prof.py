@@ -30,7 +30,7 @@ PHASE_OF = {
     "k_rootk": "flatten_number",
     "k_labk_rest": "border", "k_border": "border", "k_border_list": "border",
     "k_output": "output", "k_out_scatter": "out_scatter", "k_out_write": "out_write",
-    "k_icp_pass": "icp", "k_icp_step": "icp", "k_model32": "icp", "k_absmax": "icp",
+    "k_icp_pass": "icp", "k_icp_pass_small": "icp", "k_icp_step": "icp", "k_model32": "icp", "k_absmax": "icp",
 }
 
 

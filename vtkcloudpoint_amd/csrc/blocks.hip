@@ -207,16 +207,16 @@ __global__ __launch_bounds__(BT) void k_minmax2_final(const double* __restrict__
 __global__ __launch_bounds__(BT) void k_sortkey(const double* __restrict__ motor, int64_t n, double x_Min, double y_Min,
                                                uint64_t* __restrict__ key, uint32_t* __restrict__ idx,
                                                unsigned long long* __restrict__ orand) {
-  int64_t i = (int64_t)blockIdx.x * BT + threadIdx.x;
   unsigned long long ko = 0ull, ka = ~0ull;
-  if (i < n) {
-    double2 v = *reinterpret_cast<const double2*>(motor + 2 * i);
+  for (int64_t i = (int64_t)blockIdx.x * BT + threadIdx.x; i < n; i += (int64_t)gridDim.x * BT) {  // <= 2048 workgroups:
+    double2 v = *reinterpret_cast<const double2*>(motor + 2 * i);                                    // 2 atomics each
     double a = v.x - x_Min, b = v.y - y_Min;
     double d = a > b ? a : b;  // Math.Max on finite values
     const uint64_t k = (uint64_t)__double_as_longlong(d + 0.0);
     key[i] = k;
     idx[i] = (uint32_t)i;
-    ko = ka = k;
+    ko |= k;
+    ka &= k;
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) {
@@ -624,7 +624,7 @@ int blocks_begin(vcp_ctx* ctx, const double* d_motor_in, bool from_host, const d
   unsigned long long* orand = s->orand.as<unsigned long long>();
   VCP_HIP(ctx, hipMemsetAsync(orand, 0, 32 * 8, st));
   VCP_HIP(ctx, hipMemsetAsync(orand + 32, 0xFF, 32 * 8, st));
-  hipLaunchKernelGGL(k_sortkey, dim3(nblk(n)), dim3(BT), 0, st, motor, n, s->x_Min, s->y_Min, s->tmp0.as<uint64_t>(),
+  hipLaunchKernelGGL(k_sortkey, dim3(vcp_blocks(n, BT, 2048)), dim3(BT), 0, st, motor, n, s->x_Min, s->y_Min, s->tmp0.as<uint64_t>(),
                      s->tmp2.as<uint32_t>(), orand);
   int bit_lo = 0, bit_hi = 64;
   {

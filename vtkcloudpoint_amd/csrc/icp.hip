@@ -37,6 +37,7 @@ struct IcpState {
   double d, pre_d;
   double sums[16];
   double cen[3], mmax;  // centre of the model's bounding box and its half extent: frame and scale of the screening
+  double V[16];         // eigenvector basis of the last Horn solve (all zero = none yet)
   int round, done, failed, pad;
 };
 
@@ -499,11 +500,8 @@ __host__ __device__ inline void jrot(double (&A)[4][4], double (&V)[4][4]) {
   }
 }
 
+// A = V0^T Q V0 and V = V0 on entry (V0 = identity for a cold start): on return the columns of V are eigenvectors of Q
 __host__ __device__ inline void jacobi4(double (&A)[4][4], double (&V)[4][4]) {
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) V[i][j] = i == j ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 60; sweep++) {
     double off = 0.0, diag = 0.0;
 #pragma unroll
@@ -524,7 +522,11 @@ __host__ __device__ inline void jacobi4(double (&A)[4][4], double (&V)[4][4]) {
   }
 }
 
-__host__ __device__ inline bool horn(const double s[16], long long nd, double R1[9], double T1[3]) {
+// Vst [16]: the eigenvector basis of the previous round (row major), or NULL.  Consecutive rounds of an ICP solve
+// nearly the same 4x4 problem, so the sweeps start from the previous basis (A = V^T Q V is then almost diagonal: one
+// or two sweeps instead of six or seven -- the Jacobi chain is what bounds k_icp_step); the basis found is stored back.
+// A basis that is not finite or has drifted from orthonormal (first round, failed round) is replaced by the identity.
+__host__ __device__ inline bool horn(const double s[16], long long nd, double R1[9], double T1[3], double* Vst) {
   const double N = (double)nd;
   double muP[3], muY[3], m[3][3];
   for (int a = 0; a < 3; a++) {
@@ -541,7 +543,60 @@ __host__ __device__ inline bool horn(const double s[16], long long nd, double R1
     Q[0][i + 1] = Q[i + 1][0] = delta[i];
     for (int j = 0; j < 3; j++) Q[i + 1][j + 1] = m[i][j] + m[j][i] - (i == j ? tr : 0.0);
   }
+  bool warm = Vst != nullptr;
+  if (warm) {
+    double dev = 0.0;  // | V^T V - I |_max
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        V[i][j] = Vst[4 * i + j];
+      }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = i; j < 4; j++) {
+        double d = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) d += V[k][i] * V[k][j];
+        dev = fmax(dev, fabs(d - (i == j ? 1.0 : 0.0)));
+      }
+    warm = dev <= 1e-9;  // false for NaN too
+  }
+  if (warm) {
+    double QV[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        double d = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) d += Q[i][k] * V[k][j];
+        QV[i][j] = d;
+      }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = i; j < 4; j++) {
+        double d = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) d += V[k][i] * QV[k][j];
+        Q[i][j] = d;
+        Q[j][i] = d;
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) V[i][j] = i == j ? 1.0 : 0.0;
+  }
   jacobi4(Q, V);
+  if (Vst) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) Vst[4 * i + j] = V[i][j];
+  }
   // eigenvector of the largest eigenvalue, picked without dynamic indexing (first maximum wins)
   double ev = Q[0][0];
   double q[4] = {V[0][0], V[1][0], V[2][0], V[3][0]};
@@ -611,7 +666,7 @@ __device__ __forceinline__ void icp_step_body(const double* __restrict__ partial
   double S[16];
   for (int k = 0; k < 16; k++) S[k] = tot[k];
   double R1[9], T1[3];
-  const bool ok = horn(S, a.nd, R1, T1);
+  const bool ok = horn(S, a.nd, R1, T1, st->V);
   const double pre_d = st->d;
   const double d = S[15];
   st->pre_d = pre_d;

@@ -124,8 +124,10 @@ int vcp_nngrid_build(vcp_ctx* ctx, const double* d_pts, int64_t n, NNGrid* out) 
       npos++;
     }
   }
-  // about one point per cell over the axes that have extent; never more than 8 n + 64 cells
-  double hh = npos ? std::pow(vol / (double)n, 1.0 / npos) : 1.0;
+  // about four cells per point over the axes that have extent (never more than 8 n + 64 cells): the sets this serves are
+  // clustered -- centroids of the fragments of a few hundred blobs -- so at one point per cell on AVERAGE the occupied
+  // cells hold hundreds; the doubling rings step over the empty ones cheaply
+  double hh = npos ? std::pow(vol / (4.0 * (double)n), 1.0 / npos) : 1.0;
   if (!(hh > 0.0) || !std::isfinite(hh)) hh = 1.0;
   int64_t ncells = 0;
   for (int it = 0; it < 200; it++) {

@@ -3,7 +3,7 @@
 // Used where the reference scans a whole list per query: ICP.FindClosestPointSet (BaseClass/ICP.cs:224-250) once the
 // model has thousands of points (MainForm.ICP's real use: cluster centroids against the truth list, FrmMain.cs:841-907)
 // and RecorrectMatchingPtsByDistance (FrmMain.cs:3588-3618).  The set is binned once per call (it does not move); a
-// query searches the cells within Chebyshev distance r = 1, 2, 4, 8 of its own cell and stops as soon as the best
+// query searches the cells within Chebyshev distance r = 1, 2, 4, ... (while the block is small against the grid) of its own cell and stops as soon as the best
 // distance found is provably smaller than anything outside the searched block (every unexplored point lies at least
 // r * h away), falling back to a scan of the whole set.  Candidates are evaluated with the reference's own binary64
 // expression and compared as (value, original index) pairs, so the result is the index the sequential strict-`<`
@@ -93,10 +93,14 @@ __device__ __forceinline__ void query(const NNGrid& g, const double* p, int sub,
       }
     }
   };
-  for (int r = 1; r <= 8; r <<= 1) {
+  for (int r = 1; r <= 64; r <<= 1) {
     const int x0 = max(cx - r, 0), x1 = min(cx + r, g.D[0] - 1);
     const int y0 = max(cy - r, 0), y1 = min(cy + r, g.D[1] - 1);
     const int z0 = max(cz - r, 0), z1 = min(cz + r, g.D[2] - 1);
+    // a block of half the grid or more: the linear scan of the whole set below is the cheaper way to finish (the rings
+    // keep doubling while they are small against the set: a query with no neighbour nearby -- the first rounds of an
+    // ICP that starts far off -- used to fall from r = 8 straight to the whole set)
+    if (r > 1 && 2ll * (x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1) > (long long)g.ncells) break;
     int turn = 0;
     for (int z = z0; z <= z1; z++)
       for (int y = y0; y <= y1; y++, turn++) {

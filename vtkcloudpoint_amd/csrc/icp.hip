@@ -8,7 +8,7 @@
 //   k_icp_step  fixed-order reduction of the partial rows (bitwise reproducible, no float atomics), then ONE
 //               thread solves Horn's closed form (the INTENDED arithmetic of :53-124), applies
 //               the stop rule (:149,:180) and composes R <- R1 R, T <- R1 T + T1 (:149-177) in the state.
-// The host enqueues rounds in batches of 8 and reads the 300-byte state back once per batch; kernels of rounds
+// The host enqueues rounds in batches of 8 and reads the 430-byte state back once per batch; kernels of rounds
 // after the stop see state.done and return at once.
 //
 // Nearest neighbour: the model index is wave-uniform, so model points come through the scalar cache, four per

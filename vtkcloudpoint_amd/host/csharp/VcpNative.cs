@@ -20,6 +20,7 @@ namespace vtkPointCloud
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern void vcp_destroy(IntPtr ctx);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern IntPtr vcp_last_error(IntPtr ctx);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_release_workspace(IntPtr ctx);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_selftest_scan_dev(IntPtr ctx, IntPtr d_in, IntPtr d_out, long n, int op, out uint total);
 
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_dbscan(IntPtr ctx, double[] coords, long n, int dim, int metric,
             double eps, int min_pts, int cf_in, byte[] in_mask, byte[] in_classed, int[] labels, byte[] is_core,

@@ -1,26 +1,31 @@
 // dbscan.hip -- DBImproved.dbscan on MI355X (gfx950).
 //
 // Semantics: BaseClass/DBImproved.cs:14-114 in the order-free form of SURVEY.md 8a row A3 (see
-// include/vcp.h).  All distance arithmetic is binary64 with FMA contraction OFF, so the `d <= eps`
-// predicate is bit-identical to the C#'s (SSE2) evaluation; the grid only proposes candidates and is
-// conservative by construction (cell edge = eps * (1 + 2^-20), candidates re-tested exactly).
+// include/vcp.h).  The `d <= eps` predicate is decided on binary32 copies of the coordinates wherever that decision is
+// provably the binary64 one (screen_bounds / within_scr) and re-evaluated in binary64 with FMA contraction OFF -- the
+// C#'s (SSE2) evaluation -- everywhere else; the grid only proposes candidates and is conservative by construction
+// (cell edge = eps + the rounding of the binary32 coordinates it bins on, candidates re-tested).
 //
-// Data layout in HBM (n points, original index i, sorted position p, GD = dimension of the metric):
-//   cellof  [n] u32, skey [n] u32   cell id by original index / in cell order (rocPRIM radix sort of
-//                            (cell id, index) pairs; points excluded from a grouped call sort last)
-//   cellcnt [ncells+1] u32   first sorted position of each cell (marks of the cell ends, exclusive max-scan)
-//   pos     [n] u32          sorted position of original index i (NONE = excluded from this call)
-//   sorted  [nin*GD] f64     coordinates in cell order (x-fastest linear cell id)
+// Data layout in HBM (n points, original index i, cell-ordered position p, GD = dimension of the metric):
+//   cellcnt [ncells+1] u32   first position of each cell (x-fastest linear cell id)
+//   sorted32[nin] f32x2 / x4 coordinates relative to the grid origin in binary32, cell order: binning and screening
+//   (binary64 coordinates)   read through ExactSrc: the caller's array by index after the partition build
+//                            (gridbuild.hip), a cell-ordered copy `sorted` after the sort-based build (grids too large
+//                            for the partition: cellof / skey = cell ids by index / in cell order, rocPRIM radix sort)
+//   pos     [n] u32          position of original index i (NONE = excluded from this call); not built when the output
+//                            goes through the partition's windows
 //   sord    [nin] u32        "list position" of the point (original index, or the caller's ord)
 //   sgroup  [nin] i32        group (block) of the point, grouped calls only
-//   flags   [nin] u8         bit0 core, bit1 classed on entry, bit2 expanding, bit3 border candidate
+//   flags   [nin] u8         bit0 core, bit1 classed on entry, bit2 expanding, bit3 border candidate; high nibble:
+//                            number of recorded neighbours (nbr / nboff: the lists, packed per block of 256 positions)
 //   wlE, wlB                 position-ordered work lists: expanding points; non-core points with a neighbour
-//   parent  [nin] u32        union-find over sorted positions (pointers only decrease); NONE = not expanding
+//   parent  [nin] u32        union-find over positions (pointers only decrease); NONE = not expanding
 //   minord  [nin] u32        per root: smallest list position in the component (= the seed)
 //   seedflag[n/32] u32       bitmap of seed list positions; seedpref = popcount prefix per word
 //   rootk   [nin] u32        seed rank of the point's cluster (NONE = not expanding); clseed [K]: seed per rank
 //   labk    [nin] u32        per point: (1 + seed rank of its final cluster, 0 = none) << 2 | core | classed<<1
-// Passes: bounds -> cell keys -> sort -> cell starts -> gather -> core -> union -> flatten/number -> border -> output.
+// Passes: bounds -> grid build (partition, or cell keys / sort / cell starts / gather) -> core count + lists + work
+// lists -> union -> flatten / number -> border -> output.
 #include <string.h>
 
 #include <cmath>

@@ -72,3 +72,30 @@ def test_l2_3d_4m_vs_oracle(vcp_ctx, oracle):
     o = oracle.dbscan(d["xyz"], d["eps_l2"], d["min_pts"], oracle.L2_3D)
     g = vcp_ctx.dbscan(d["xyz"], d["eps_l2"], d["min_pts"], N.L2_3D)
     assert np.array_equal(g["labels"], o["labels"]) and g["cf"] == o["cf"] and g["evals"] == o["evals"]
+
+
+@pytest.mark.parametrize("n", [5_000_000, 8_388_608 + 12_345])
+def test_output_window_sizes_between_the_tested_clouds(vcp_ctx, oracle, n):
+    """The output pass picks its window (2^13 / 2^14 / 2^15 list positions) by cloud size; 1 M / 4 M / 10 M clouds leave
+    the 2^14 form and the 2^15 threshold itself untested.  With and without an isClassed input (in/out labels), and
+    through device pointers that are NOT 16-byte aligned (the scalar stores of the write pass)."""
+    import torch
+    d = synth.config_cloud(n, seed=21)
+    motor = d["motor"]
+    o = oracle.dbscan(motor, d["eps_l1"], d["min_pts"], oracle.L1_2D)
+    g = vcp_ctx.dbscan(motor, d["eps_l1"], d["min_pts"], N.L1_2D)
+    assert np.array_equal(g["labels"], o["labels"]) and g["cf"] == o["cf"] and g["evals"] == o["evals"]
+    assert np.array_equal(g["is_core"], o["is_key"]) and np.array_equal(g["is_classed"], o["classed"])
+    # device-resident call with label / flag arrays offset by one element
+    dm = torch.from_numpy(motor).cuda()
+    lab = torch.zeros(n + 4, dtype=torch.int32, device="cuda")
+    core = torch.zeros(n + 4, dtype=torch.uint8, device="cuda")
+    cls = torch.zeros(n + 4, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    cf, ev = vcp_ctx.dbscan_dev(dm.data_ptr(), n, 2, d["eps_l1"], d["min_pts"], N.L1_2D, 0, None, lab.data_ptr() + 4,
+                                core.data_ptr() + 1, cls.data_ptr() + 1)
+    assert cf == o["cf"] and ev == o["evals"]
+    assert np.array_equal(lab[1:n + 1].cpu().numpy(), o["labels"])
+    assert np.array_equal(core[1:n + 1].cpu().numpy(), o["is_key"])
+    assert np.array_equal(cls[1:n + 1].cpu().numpy(), o["classed"])
+    assert int(lab[0]) == 0 and int(lab[n + 1]) == 0 and int(core[0]) == 0 and int(core[n + 1]) == 0

@@ -194,7 +194,8 @@ int vcp_blocks_finish_dev(vcp_ctx* ctx, const int32_t* d_local, int64_t evals_bl
  *            the border rule (:87, largest adjacent id) and writes d_labels [n], d_is_classed [n] (may be
  *            NULL); *twice = own points (own_lo <= ord < own_lo + own_count) that the C# loop queries a
  *            second time (the iritatorNum term).
- * The state lives in the context's workspace: no other call on this context between begin and finish. */
+ * The state lives in the context's workspace: no other call on this context between begin and finish, and d_coords
+ * (read in place by the exact re-tests of the finish stage too) stays valid and unchanged until finish has returned. */
 int vcp_slab_begin(vcp_ctx* ctx, const double* d_coords, int64_t n, int dim, int metric, double eps,
                    int min_pts, const uint8_t* d_noexpand, const uint32_t* d_ord, uint32_t* d_rep,
                    uint8_t* d_is_core, int64_t* n_comp);

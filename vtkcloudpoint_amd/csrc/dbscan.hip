@@ -66,6 +66,7 @@ struct SlabState {
   GridP g;
   double thr = 0.0;
   Screen sc{-1.0f, INFINITY};
+  ExactSrc xs{nullptr, nullptr, 0};  // where the binary64 coordinates are: the caller's d_coords stay valid until finish
   unsigned nb = 0;
 };
 
@@ -315,19 +316,6 @@ __global__ __launch_bounds__(TPB) void k_cellstart_tiles(const uint32_t* __restr
   // coalesced store; cells up to and including index ncells (= number of included points) exist in the table
   for (int k = threadIdx.x; k < CTILE; k += TPB)
     if (c0 + (uint32_t)k <= ncells) cellstart[c0 + k] = cnt[at(k)];
-}
-
-// cell-ordered binary64 copy after a partition build, for the staged calls (vcp_slab_*): their second stage runs in a
-// later call, when the caller's array need no longer be there
-template <int GD>
-__global__ __launch_bounds__(TPB) void k_exact_copy(ExactSrc xs, const uint32_t* __restrict__ cellstart, uint32_t ncells,
-                                                   double* __restrict__ sorted) {
-  const uint32_t nin = cellstart[ncells];
-  const int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
-  if (p >= nin) return;
-  double q[3];
-  load_exact<GD>(xs, (uint32_t)p, q);
-  store_pt<GD>(sorted, p, q);
 }
 
 template <int GD, bool GROUPED>
@@ -1772,10 +1760,9 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   VCP_TRY(vcp_ensure(ctx, ctx->b_rank, (size_t)n * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_pos, (size_t)n * 4));
   // cell order comes from the two-level partition (gridbuild.hip) unless the grid is too large for its one-level coarse
-  // split; only the sort-based build and the staged calls keep a cell-ordered binary64 copy
+  // split; only the sort-based build keeps a cell-ordered binary64 copy
   const bool part = vcp_grid_partition_fits(n, g.ncells);
-  const bool staged = ext && ext->slab;
-  if (!part || staged) VCP_TRY(vcp_ensure(ctx, ctx->b_sorted, (size_t)n * GD * 8));
+  if (!part) VCP_TRY(vcp_ensure(ctx, ctx->b_sorted, (size_t)n * GD * 8));
   VCP_TRY(vcp_ensure(ctx, ctx->b_sorted32, (size_t)n * (GD == 2 ? 2 : 4) * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_sidx, (size_t)n * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_flags, (size_t)n));
@@ -1842,11 +1829,7 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
     ga.flags = flags;
     ga.pos = part_out ? nullptr : pos;
     VCP_TRY(vcp_grid_build_partition(ctx, ga));
-    xs = ExactSrc{d_coords, d_ord ? cellof : sord, stride};
-    if (staged) {
-      hipLaunchKernelGGL(k_exact_copy<GD>, dim3(nb), dim3(TPB), 0, st, xs, cellcnt, g.ncells, sorted);
-      xs = ExactSrc{sorted, nullptr, GD};
-    }
+    xs = ExactSrc{d_coords, d_ord ? cellof : sord, stride};  // staged calls: kept for vcp_slab_finish (SlabState.xs)
   } else {
     vcp_phase(ctx, "cell_key");
     VCP_TRY(vcp_ensure(ctx, ctx->b_skey, (size_t)n * 4));
@@ -1956,6 +1939,7 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
     ss.g = g;
     ss.thr = thr;
     ss.sc = sc;
+    ss.xs = xs;
     ss.nb = nb;
     if (cf_out) *cf_out = (int32_t)hn[0];
     return VCP_OK;
@@ -2031,7 +2015,6 @@ int run_slab_finish(vcp_ctx* ctx, const SlabState& ss, const uint32_t* d_map_rep
   const GridP g = ss.g;
   uint32_t* cellcnt = ctx->b_cellcnt.as<uint32_t>();
   uint32_t* pos = ctx->b_pos.as<uint32_t>();
-  double* sorted = ctx->b_sorted.as<double>();
   uint32_t* sord = ctx->b_sidx.as<uint32_t>();
   uint8_t* flags = ctx->b_flags.as<uint8_t>();
   uint32_t* parent = ctx->b_parent.as<uint32_t>();
@@ -2055,7 +2038,7 @@ int run_slab_finish(vcp_ctx* ctx, const SlabState& ss, const uint32_t* d_map_rep
                      (uint32_t)ss.n_comp, rootk, counters);
   vcp_phase(ctx, "border");
   hipLaunchKernelGGL(k_labk_rest, dim3(nb), dim3(TPB), 0, st, flags, parent, rootk, labk, cellcnt, g.ncells);
-  hipLaunchKernelGGL((k_border<GD, METRIC, false>), dim3(nbl), dim3(TPB), 0, st, ExactSrc{sorted, nullptr, GD}, g, ss.thr,
+  hipLaunchKernelGGL((k_border<GD, METRIC, false>), dim3(nbl), dim3(TPB), 0, st, ss.xs, g, ss.thr,
                      cellcnt, nullptr, flags, parent, sord, rootk, clseed, labk, counters, nullptr, wlB, own_lo, own_span,
                      ctx->b_sorted32.as<float>(), ss.sc);
   vcp_phase(ctx, "output");

@@ -1,0 +1,257 @@
+"""A SECOND, independent transcription of the reference's DBImproved (BaseClass/DBImproved.cs:14-114) -- pure Python,
+written from the C# text without looking at oracle/vcp_oracle.cpp -- against the oracle's literal C++ transcription.
+The reference cannot be compiled or run here (parity unpinned by the reference); two transcriptions
+made independently that agree on every output, including the iritatorNum count and the growth of the neighbour list
+with duplicates (the boxed-reference comparison at :76 is never true), is the strongest pin available."""
+import numpy as np
+import pytest
+
+
+class P:  # Point3D: the members the path touches (BaseClass/DataModel.cs:102-160)
+    __slots__ = ("motor_x", "motor_y", "clusterId", "isClassed", "isKeyPoint", "index")
+
+    def __init__(self, x, y, cid=0, classed=False):
+        self.motor_x, self.motor_y, self.clusterId, self.isClassed, self.isKeyPoint = x, y, cid, classed, False
+
+
+class DBImprovedPy:
+    iritatorNum = 0  # static
+
+    def __init__(self, cf=0):
+        self.clusterAmount = 0
+        self.pointsAmount = 0
+        self.cf = cf
+
+    @staticmethod
+    def getDisP(p1, p2):  # :14-25
+        dx = p1.motor_x - p2.motor_x
+        dy = p1.motor_y - p2.motor_y
+        DBImprovedPy.iritatorNum += 1
+        return abs(dx) + abs(dy)
+
+    @staticmethod
+    def isKeyPoint(lst, p, e, minPts):  # :33-54
+        count = 0
+        tmp = []
+        for i in range(len(lst)):
+            if DBImprovedPy.getDisP(p, lst[i]) <= e:
+                count += 1
+                tmp.append([i])  # a BOXED int: a fresh object per Add
+        if count >= minPts:
+            p.isKeyPoint = True
+        return tmp
+
+    @staticmethod
+    def expandCluster(p, nei, c, e, minPts, lst):  # :56-90
+        p.clusterId = c
+        i = 0
+        while i < len(nei):  # nei.Count is re-read every trip
+            dpp = lst[nei[i][0]]
+            if not dpp.isClassed:
+                dpp.isClassed = True
+                tmp = DBImprovedPy.isKeyPoint(lst, dpp, e, minPts)
+                if len(tmp) >= minPts:
+                    for k in range(len(tmp)):
+                        flag = False
+                        for j in range(len(nei)):
+                            if nei[j] is tmp[k]:  # object == object on boxed ints: reference equality
+                                flag = True
+                                break
+                        if not flag:
+                            nei.append(tmp[k])
+            dpp.clusterId = c
+            i += 1
+
+    def dbscan(self, lst, e, minPts):  # :91-114
+        for i in range(len(lst)):
+            dpp = lst[i]
+            self.pointsAmount += 1
+            if dpp.isClassed:
+                continue
+            tmp = DBImprovedPy.isKeyPoint(lst, dpp, e, minPts)
+            if len(tmp) >= minPts:
+                self.cf += 1
+                DBImprovedPy.expandCluster(dpp, tmp, self.cf, e, minPts, lst)
+        self.clusterAmount = self.cf
+
+
+def run_py(c, eps, mp, cf_in, cls, lab0):
+    pts = [P(float(c[i, 0]), float(c[i, 1]), 0 if lab0 is None else int(lab0[i]), False if cls is None else bool(cls[i]))
+           for i in range(len(c))]
+    DBImprovedPy.iritatorNum = 0
+    db = DBImprovedPy(cf_in)
+    db.dbscan(pts, eps, mp)
+    return dict(labels=np.array([p.clusterId for p in pts], np.int32), classed=np.array([p.isClassed for p in pts], np.uint8),
+                is_key=np.array([p.isKeyPoint for p in pts], np.uint8), cf=db.clusterAmount,
+                evals=DBImprovedPy.iritatorNum, points=db.pointsAmount)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_two_transcriptions_agree(oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    for trial in range(120):
+        n = int(rng.integers(0, 45))
+        if trial % 4 == 0:
+            c = rng.integers(0, 7, size=(n, 2)).astype(np.float64) * 0.5      # lattice: exact d == eps ties, duplicates
+        else:
+            c = np.round(rng.normal(0, 1.2, size=(n, 2)) * 8) / 8
+        if trial % 11 == 0 and n:
+            c[rng.integers(0, n)] = np.nan                                       # a point that is not its own neighbour
+        eps = float(rng.choice([0.5, 1.0, 1.5, 0.0, 0.25]))
+        mp = int(rng.integers(0, 6))
+        cf = int(rng.integers(0, 4))
+        if trial % 3 == 0 and n:
+            cls = (rng.random(n) < 0.2).astype(np.uint8)
+            lab0 = (rng.integers(1, 5, n) * cls).astype(np.int32)
+        else:
+            cls, lab0 = None, None
+        a = run_py(c, eps, mp, cf, cls, lab0)
+        o = oracle.dbscan(c, eps, mp, oracle.L1_2D, cf, cls, lab0, literal=True, dedupe=bool(trial % 2))
+        tag = "seed %d trial %d" % (seed, trial)
+        assert np.array_equal(a["labels"], o["labels"]), tag
+        assert np.array_equal(a["classed"], o["classed"]), tag
+        assert np.array_equal(a["is_key"], o["is_key"]), tag
+        assert a["cf"] == o["cf"] and a["evals"] == o["evals"], tag
+
+
+# ---- the block pipeline: getClusterFromMotor (FrmMain.cs:1214-1291), DoWork3 (:1340-1361), StartCode (:2782-2794),
+# CompleteWork3 (:1442-1520)
+class OutOfRange(Exception):
+    pass
+
+
+def block_pipeline_py(motor, eps, min_pts, pts_in_cell):
+    """Second transcription, with the declared deviations of DESIGN.md section 2 applied (stable sorts; a block-0 point is
+    not filed under a rectangle as well; clusterSum summed in block order)."""
+    n = len(motor)
+    raw = [P(float(motor[i, 0]), float(motor[i, 1])) for i in range(n)]
+    for i, p in enumerate(raw):
+        p.index = i
+    x_Min = min(p.motor_x for p in raw)
+    y_Min = min(p.motor_y for p in raw)
+    x_Max = max(p.motor_x for p in raw)
+    y_Max = max(p.motor_y for p in raw)
+    raw.sort(key=lambda p: max(p.motor_x - x_Min, p.motor_y - y_Min))  # :1229-1251 (stable)
+    cell = raw[:pts_in_cell]
+    cell_x = max(p.motor_x for p in cell) - x_Min
+    cell_y = max(p.motor_y for p in cell) - y_Min
+    with np.errstate(divide="ignore", invalid="ignore"):
+        fr = np.float64(y_Max - y_Min) / np.float64(cell_y)
+        fc = np.float64(x_Max - x_Min) / np.float64(cell_x)
+    if not (np.isfinite(fr) and np.isfinite(fc)):
+        raise ZeroDivisionError
+    rows, cols = int(fr) + 1, int(fc) + 1
+    first = set(id(p) for p in cell)
+
+    def by_scale(min_x, min_y, max_x, max_y):  # Tools.getListByScale2, Tools.cs:510-513
+        return [p for p in raw if id(p) not in first and p.motor_x > min_x and p.motor_y > min_y
+                and p.motor_x <= max_x and p.motor_y <= max_y]
+
+    cells = [None] * (rows * cols)
+    cells[0] = cell
+    index = 0
+    for p in range(rows):
+        for q in range(cols):
+            if index == 0:
+                index += 1
+                continue
+            lo_x, lo_y = x_Min + q * cell_x, y_Min + p * cell_y
+            if p == rows - 1 and q != cols - 1:
+                cells[index] = by_scale(lo_x, lo_y, x_Min + (q + 1) * cell_x, y_Max)
+            elif p != rows - 1 and q == cols - 1:
+                cells[index] = by_scale(lo_x, lo_y, x_Max, y_Min + (p + 1) * cell_y)
+            elif p == rows - 1 and q == cols - 1:
+                cells[index] = by_scale(lo_x, lo_y, x_Max, y_Max)
+            else:
+                cells[index] = by_scale(lo_x, lo_y, x_Min + (q + 1) * cell_x, y_Min + (p + 1) * cell_y)
+            index += 1
+    block_of = np.full(n, -1, np.int32)
+    for b, c in enumerate(cells):
+        for p in c:
+            block_of[p.index] = b
+    # DoWork3 (:1340-1361: clusterSum = 1 before the pool threads add to it), StartCode per cell
+    DBImprovedPy.iritatorNum = 0
+    clusterSum = 1
+    for c in cells:
+        db = DBImprovedPy()
+        db.dbscan(c, eps, min_pts)
+        clusterSum += db.clusterAmount
+    # CompleteWork3
+    idNow, clusLen, delSum = 0, 0, 0
+    merge = []
+    for c in cells:
+        if len(c) == 0:
+            continue
+        c.sort(key=lambda p: p.clusterId)  # :1449 (stable)
+        idLast = c[0].clusterId
+        if idLast != 0:
+            idNow += 1
+            clusLen = 1
+        else:
+            clusLen = 0
+        for pt in c:
+            cid = pt.clusterId
+            if cid == 0:
+                merge.append(pt)
+            else:
+                if cid != idLast:
+                    if clusLen <= 3 and idLast != 0:
+                        delSum += 1
+                        for k in range(clusLen):
+                            at = len(merge) - 1 - k
+                            if at < 0:
+                                raise OutOfRange()  # List<T> indexer: ArgumentOutOfRangeException
+                            merge[at].clusterId = 0
+                    else:
+                        idNow += 1
+                    clusLen = 1
+                else:
+                    clusLen += 1
+                pt.clusterId = idNow
+                merge.append(pt)
+                idLast = cid
+    dbb = DBImprovedPy()
+    dbb.clusterAmount = clusterSum - delSum
+    dbb.cf = clusterSum - delSum - 1
+    kept = dbb.cf
+    zero = [p for p in merge if p.clusterId == 0]
+    merge = [p for p in merge if p.clusterId != 0]
+    for p in zero:
+        p.isClassed = False
+    dbb.dbscan(zero, eps, min_pts)
+    merge += zero
+    labels = np.zeros(n, np.int32)
+    for p in merge:
+        labels[p.index] = p.clusterId
+    return dict(labels=labels, block_of=block_of, order=np.array([p.index for p in merge], np.int64), rows=rows, cols=cols,
+                kept=kept, del_sum=delSum, cluster_amount=dbb.clusterAmount, evals=DBImprovedPy.iritatorNum)
+
+
+def test_block_pipeline_two_transcriptions_agree(oracle):
+    rng = np.random.default_rng(77)
+    done = thrown = 0
+    for trial in range(150):
+        n = int(rng.integers(1, 140))
+        if trial % 3 == 0:
+            m = rng.integers(0, 9, size=(n, 2)).astype(np.float64) * 0.5
+        else:
+            m = np.round(np.concatenate([rng.normal(0, 0.4, (n // 2, 2)), rng.uniform(-3, 3, (n - n // 2, 2))]) * 16) / 16
+        eps = float(rng.choice([0.25, 0.5, 1.0]))
+        mp = int(rng.integers(1, 5))
+        pic = int(rng.integers(1, 25))
+        try:
+            a = block_pipeline_py(m, eps, mp, pic)
+        except (ZeroDivisionError, OutOfRange):
+            with pytest.raises(Exception):
+                oracle.block_pipeline(m, eps, mp, pic, 3, canonical=False, brute=True)
+            thrown += 1
+            continue
+        o = oracle.block_pipeline(m, eps, mp, pic, 3, canonical=False, brute=True)
+        tag = "trial %d" % trial
+        for k in ("rows", "cols", "kept", "del_sum", "cluster_amount", "evals"):
+            assert a[k] == o[k], (tag, k, a[k], o[k])
+        assert np.array_equal(a["block_of"], o["block_of"]), tag
+        assert np.array_equal(a["labels"], o["labels"]), tag
+        assert np.array_equal(a["order"], o["order"]), tag
+        done += 1
+    assert done > 100 and thrown > 0

@@ -255,3 +255,67 @@ def test_block_pipeline_two_transcriptions_agree(oracle):
         assert np.array_equal(a["order"], o["order"]), tag
         done += 1
     assert done > 100 and thrown > 0
+
+
+# ---- ICP.go_hell_ICP (BaseClass/ICP.cs:18-181): loop structure, composition order and stop rule as written; the Horn
+# solve in its INTENDED arithmetic through numpy's symmetric eigen solver instead of Jacobi sweeps
+def icp_py(model, data, e, max_round=200):
+    R = np.zeros((3, 3))  # the caller's matrices: untouched when round 1 already stops
+    T = np.zeros(3)
+    pre_d = d = 0.0
+    rnd = 0
+    P = data.copy()
+    while True:
+        pre_d = d
+        # FindClosestPointSet :224-250: strict `<`, seeded with model[0] -> lowest index among equal distances
+        dd = ((P[:, None, :] - model[None, :, :]) ** 2)
+        dist = dd[:, :, 0] + dd[:, :, 1] + dd[:, :, 2]
+        Y = model[np.argmin(dist, axis=1)]
+        muP, muY = P.mean(axis=0), Y.mean(axis=0)
+        cov = (P.T @ Y) / len(P) - np.outer(muP, muY)
+        A = cov - cov.T
+        delta = np.array([A[1, 2], A[2, 0], A[0, 1]])
+        tr = np.trace(cov)
+        Q = np.zeros((4, 4))
+        Q[0, 0] = tr
+        Q[0, 1:] = delta
+        Q[1:, 0] = delta
+        Q[1:, 1:] = cov + cov.T - tr * np.eye(3)
+        w, V = np.linalg.eigh(Q)
+        q = V[:, np.argmax(w)]
+        R1 = np.array([  # CalculateRotation :274-285
+            [q[0] * q[0] + q[1] * q[1] - q[2] * q[2] - q[3] * q[3], 2.0 * (q[1] * q[2] - q[0] * q[3]), 2.0 * (q[1] * q[3] + q[0] * q[2])],
+            [2.0 * (q[1] * q[2] + q[0] * q[3]), q[0] * q[0] - q[1] * q[1] + q[2] * q[2] - q[3] * q[3], 2.0 * (q[2] * q[3] - q[0] * q[1])],
+            [2.0 * (q[1] * q[3] - q[0] * q[2]), 2.0 * (q[2] * q[3] + q[0] * q[1]), q[0] * q[0] - q[1] * q[1] - q[2] * q[2] + q[3] * q[3]]])
+        T1 = muY - R1 @ muP
+        d = float((((P - Y) ** 2).sum(axis=1)).sum())
+        rnd += 1
+        if abs(d - pre_d) >= e:
+            if rnd == 1:
+                R, T = R1.copy(), T1.copy()
+            else:
+                R, T = R1 @ R, R1 @ T + T1
+            P = data @ R.T + T  # TransPoint :195-219, always from the original data
+        if not abs(d - pre_d) >= e or rnd >= max_round:
+            return dict(R=R, T=T, sse=d, iters=rnd)
+
+
+def test_icp_loop_two_transcriptions_agree(oracle):
+    rng = np.random.default_rng(5)
+    for trial in range(40):
+        nm = int(rng.integers(4, 40))
+        nd = int(rng.integers(10, 300))
+        model = rng.uniform(0, 20, (nm, 3))
+        base = model[rng.integers(0, nm, nd)] + rng.normal(0, 0.05, (nd, 3))
+        ang = np.deg2rad(rng.uniform(0, 6))
+        ax = rng.normal(size=3)
+        ax /= np.linalg.norm(ax)
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        Rt = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+        data = base @ Rt.T + rng.uniform(-0.3, 0.3, 3)
+        tol = float(rng.choice([1e-3, 1e-6, 1e-9]))
+        a = icp_py(model, data, tol)
+        o = oracle.icp(model, data, tol, 200, oracle.STOP_SSE_DELTA)
+        assert a["iters"] == o["iters"], trial
+        assert np.allclose(a["R"], o["R"], atol=1e-9) and np.allclose(a["T"], o["T"], atol=1e-8), trial
+        assert abs(a["sse"] - o["sse"]) <= 1e-9 * max(1.0, abs(o["sse"])), trial

@@ -319,3 +319,61 @@ def test_icp_loop_two_transcriptions_agree(oracle):
         assert a["iters"] == o["iters"], trial
         assert np.allclose(a["R"], o["R"], atol=1e-9) and np.allclose(a["T"], o["T"], atol=1e-8), trial
         assert abs(a["sse"] - o["sse"]) <= 1e-9 * max(1.0, abs(o["sse"])), trial
+
+
+# ---- calMatchedCoords + RecorrectMatchingPtsByDistance (FrmMain.cs:3572-3618, getDisP :829-835), GetClusList (Tools.cs:162-195)
+def test_matching_and_centroids_python_loops(oracle):
+    import math
+    rng = np.random.default_rng(31)
+    for trial in range(25):
+        K, T = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        cen = rng.integers(0, 8, (K, 3)).astype(np.float64) * 0.5 if trial % 2 else rng.uniform(0, 5, (K, 3))
+        tru = rng.integers(0, 8, (T, 3)).astype(np.float64) * 0.5 if trial % 2 else rng.uniform(0, 5, (T, 3))
+        M = np.eye(4)
+        M[:3, :3] += rng.normal(0, 0.05, (3, 3))
+        M[:3, 3] = rng.normal(0, 0.2, 3)
+        md = float(rng.choice([0.3, 1.0, 2.5]))
+        mx = np.zeros((K, 3))
+        is_m = np.zeros(K, np.uint8)
+        near = np.zeros(K, np.int32)
+        cnt = 0
+        for j in range(K):
+            for r in range(3):  # :3575-3583, left to right
+                mx[j, r] = cen[j, 0] * M[r, 0] + cen[j, 1] * M[r, 1] + cen[j, 2] * M[r, 2] + M[r, 3]
+
+            def dis(i):
+                dx, dy, dz = tru[i, 0] - mx[j, 0], tru[i, 1] - mx[j, 1], tru[i, 2] - mx[j, 2]
+                return math.sqrt(dx * dx + dy * dy + dz * dz)
+            best, c2t = 0, dis(0)
+            for i in range(T):
+                ddd = dis(i)
+                if ddd < c2t:
+                    c2t, best = ddd, i
+            near[j] = best
+            if c2t < md:
+                is_m[j] = 1
+                cnt += 1
+        o = oracle.match(cen, tru, M.reshape(16), md)
+        assert np.array_equal(o["matched_xyz"], mx) and np.array_equal(o["nearest"], near)
+        assert np.array_equal(o["is_matched"], is_m) and o["count"] == cnt
+    for trial in range(25):  # GetClusList: LINQ Average = sequential binary64 sum / count, in list order
+        n, K = int(rng.integers(1, 200)), int(rng.integers(1, 9))
+        xyz = rng.uniform(-50, 50, (n, 3))
+        motor = rng.uniform(-5, 5, (n, 2))
+        lab = rng.integers(0, K + 1, n).astype(np.int32)
+        c3, c2, counts = oracle.centroids(xyz, motor, lab, K)
+        for k in range(1, K + 1):
+            li = [i for i in range(n) if lab[i] == k]
+            assert counts[k - 1] == len(li)
+            if not li:
+                continue
+            for a in range(3):
+                sm = 0.0
+                for i in li:
+                    sm += xyz[i, a]
+                assert c3[k - 1, a] == sm / len(li)
+            for a in range(2):
+                sm = 0.0
+                for i in li:
+                    sm += motor[i, a]
+                assert c2[k - 1, a] == sm / len(li)

@@ -377,3 +377,74 @@ def test_matching_and_centroids_python_loops(oracle):
                 for i in li:
                     sm += motor[i, a]
                 assert c2[k - 1, a] == sm / len(li)
+
+
+# ---- Tools.MergeIDByDistance (Tools.cs:580-621) + refreshCensAndClusByDictionary (:521-572)
+def test_merge_and_refresh_python_transcription(oracle):
+    rng = np.random.default_rng(41)
+    for trial in range(40):
+        K = int(rng.integers(1, 25))
+        n = int(rng.integers(K, 300))
+        lab = rng.integers(0, K + 1, n).astype(np.int32)
+        lab[:K] = np.arange(1, K + 1)  # every cluster has a member (clusList position == id - 1, as the C# assumes)
+        xyz = np.round(rng.uniform(0, 6, (n, 3)) * 4) / 4
+        motor = rng.uniform(-5, 5, (n, 2))
+        thr = float(rng.choice([0.25, 0.6, 1.5]))
+        # centroids as GetClusList leaves them (sequential sums)
+        cen = []
+        for k in range(1, K + 1):
+            li = [i for i in range(n) if lab[i] == k]
+            c = [0.0, 0.0, 0.0]
+            for a in range(3):
+                sm = 0.0
+                for i in li:
+                    sm += xyz[i, a]
+                c[a] = sm / len(li)
+            cen.append(c)
+        cen = np.array(cen)
+        # MergeIDByDistance
+        pts = [P(cen[k, 0], cen[k, 1]) for k in range(K)]   # motor_x = X, motor_y = Y, clusterId = 0
+        before = list(range(1, K + 1))                        # IDBeforeMerge
+        DBImprovedPy().dbscan(pts, thr, 2)
+        dick, seen = {}, set()
+        for a, p in enumerate(pts):
+            if p.clusterId != 0:
+                if before[a] not in seen:
+                    seen.add(before[a])
+                    for b, q in enumerate(pts):
+                        if q.clusterId == p.clusterId and before[b] != before[a]:
+                            seen.add(before[b])
+                            dick[before[b]] = before[a]
+            else:
+                seen.add(before[a])
+        map_to, mc = oracle.merge_ids(cen[:, :2], np.arange(1, K + 1, dtype=np.int32), thr)
+        assert mc == len(dick)
+        assert np.array_equal(map_to, np.array([dick.get(k, 0) for k in range(1, K + 1)], np.int32)), trial
+        # refreshCensAndClusByDictionary: lists per id in rawData order, merged lists appended, removed, sorted, renumbered
+        lists = {k: [i for i in range(n) if lab[i] == k] for k in range(1, K + 1)}
+        order_ids = list(range(1, K + 1))
+        for k in order_ids:
+            if k in dick:
+                lists[dick[k]].extend(lists[k])
+        kept = sorted(k for k in order_ids if k not in dick)
+        newlab = np.zeros(n, np.int32)
+        c3, c2 = [], []
+        for new_id, k in enumerate(kept, start=1):
+            for i in lists[k]:
+                newlab[i] = new_id
+            row3, row2 = [], []
+            for a in range(3):
+                sm = 0.0
+                for i in lists[k]:
+                    sm += xyz[i, a]
+                row3.append(sm / len(lists[k]))
+            for a in range(2):
+                sm = 0.0
+                for i in lists[k]:
+                    sm += motor[i, a]
+                row2.append(sm / len(lists[k]))
+            c3.append(row3)
+            c2.append(row2)
+        lo, ko, o3, o2, oc = oracle.refresh_by_dictionary(xyz, motor, lab, K, map_to)
+        assert ko == len(kept) and np.array_equal(lo, newlab), trial
+        assert np.array_equal(o3, np.array(c3).reshape(-1, 3)) and np.array_equal(o2, np.array(c2).reshape(-1, 2)), trial

@@ -316,6 +316,9 @@ __global__ __launch_bounds__(BT) void k_gather_motor(const double* __restrict__ 
 }
 
 // ---- finish --------------------------------------------------------------------------------------
+// (One lane per position with the lanes of a block combined by ballot and ONE atomicMax / atomicAdd per wave and block
+// was measured: 443 us against 96 -- the per-block words of neighbouring blocks share cache lines and the atomics of
+// 156 k waves serialise on them.)
 // per block: K_b = max local id, Z_b = number of noise points.  One wave per block walks the block's slice of
 // the block-major label list (coalesced) and reduces in registers: no atomics.
 __global__ __launch_bounds__(BT) void k_block_stats(const int32_t* __restrict__ local, const uint32_t* __restrict__ blockstart,
@@ -522,33 +525,36 @@ __global__ __launch_bounds__(BT) void k_zero_flag(const int32_t* __restrict__ ne
 // merge_order = non-zero entries in final order, then the zero list (FrmMain.cs:1510-1520)
 __global__ __launch_bounds__(BT) void k_compact(const uint32_t* __restrict__ zflag_scan, const int32_t* __restrict__ newlab,
                                                const uint32_t* __restrict__ order, const uint32_t* __restrict__ bl,
-                                               const double* __restrict__ motor, int64_t m, uint32_t Z,
-                                               uint32_t* __restrict__ zlist, double* __restrict__ zcoords,
+                                               const double* __restrict__ motor_bm, int64_t m, uint32_t Z,
+                                               uint32_t* __restrict__ zrank, double* __restrict__ zcoords,
                                                int64_t* __restrict__ merge_order) {
   int64_t u = (int64_t)blockIdx.x * BT + threadIdx.x;
   if (u >= m) return;
   uint32_t t = order[u];
-  uint32_t i = bl[t];
   uint32_t zr = zflag_scan[u];
   if (newlab[t] == 0) {
-    zlist[zr] = i;
-    *reinterpret_cast<double2*>(zcoords + 2 * (size_t)zr) = *reinterpret_cast<const double2*>(motor + 2 * (size_t)i);
-    if (merge_order) merge_order[(m - Z) + zr] = (int64_t)i;
+    zrank[t] = zr;  // where the noise pass will leave this point's label
+    // the coordinates in block-major order: t stays inside the point's block, the original index does not
+    *reinterpret_cast<double2*>(zcoords + 2 * (size_t)zr) = *reinterpret_cast<const double2*>(motor_bm + 2 * (size_t)t);
+    if (merge_order) merge_order[(m - Z) + zr] = (int64_t)bl[t];
   } else if (merge_order) {
-    merge_order[u - zr] = (int64_t)i;
+    merge_order[u - zr] = (int64_t)bl[t];
   }
 }
-// every label by original index: block-major positions < m carry the renumbered id (0 = noise / demoted), the rest of
+// every label by original index, in ONE pass after the noise pass: block-major positions < m carry the renumbered id or,
+// for noise / demoted points, what the global noise pass gave them (zlab at their rank in the zero list); the rest of
 // the list (points in no block) 0 -- the whole array is written, nothing has to be cleared first
-__global__ __launch_bounds__(BT) void k_final_labels(const int32_t* __restrict__ newlab, const uint32_t* __restrict__ bl,
+__global__ __launch_bounds__(BT) void k_final_labels(const int32_t* __restrict__ newlab, const int32_t* __restrict__ zlab,
+                                                    const uint32_t* __restrict__ zrank, const uint32_t* __restrict__ bl,
                                                     int64_t m, int64_t n, int32_t* __restrict__ labels) {
   int64_t t = (int64_t)blockIdx.x * BT + threadIdx.x;
-  if (t < n) labels[bl[t]] = t < m ? newlab[t] : 0;
-}
-__global__ __launch_bounds__(BT) void k_scatter_zlab(const int32_t* __restrict__ zlab, const uint32_t* __restrict__ zlist,
-                                                    uint32_t Z, int32_t* __restrict__ labels) {
-  int64_t u = (int64_t)blockIdx.x * BT + threadIdx.x;
-  if (u < Z) labels[zlist[u]] = zlab[u];
+  if (t >= n) return;
+  int32_t v = 0;
+  if (t < m) {
+    v = newlab[t];
+    if (v == 0 && zlab) v = zlab[zrank[t]];
+  }
+  labels[bl[t]] = v;
 }
 
 unsigned nblk(int64_t n) { return vcp_blocks(n, BT); }
@@ -830,22 +836,21 @@ int blocks_finish(vcp_ctx* ctx, const int32_t* d_local, int64_t evals_blocks, in
   VCP_TRY(ens(ctx, s->zlist, (size_t)(Z + 1) * 4));
   VCP_TRY(ens(ctx, s->zcoords, (size_t)(Z + 1) * 16));
   VCP_TRY(ens(ctx, s->zlab, (size_t)(Z + 1) * 4));
+  uint32_t* zrank = s->tmp2.as<uint32_t>();  // [m + 1]: free again (it held the identity for the library-sort order)
   if (m > 0)
     hipLaunchKernelGGL(k_compact, dim3(nblk(m)), dim3(BT), 0, st, zflag, newlab, order, s->bl.as<uint32_t>(),
-                       s->motor_ptr, m, Z, s->zlist.as<uint32_t>(), s->zcoords.as<double>(), d_merge_order);
-  // labels by original index: kept clusters now, the noise pass result on top
-  hipLaunchKernelGGL(k_final_labels, dim3(nblk(n)), dim3(BT), 0, st, newlab, s->bl.as<uint32_t>(), m, n, d_labels);
+                       s->motor_bm.as<double>(), m, Z, zrank, s->zcoords.as<double>(), d_merge_order);
   VCP_HIP(ctx, hipGetLastError());
   // FrmMain.cs:1507-1516: one DBImproved over all noise, cf preset to the kept-cluster count
   int32_t cf = (int32_t)kept;
   int64_t ev = 0;
-  if (Z > 0) {
+  if (Z > 0)
     VCP_TRY(vcp_dbscan_engine(ctx, s->zcoords.as<double>(), (int64_t)Z, 2, VCP_L1_2D, s->eps, s->min_pts, (int32_t)kept,
                               nullptr, s->zlab.as<int32_t>(), nullptr, nullptr, &cf, &ev, nullptr));
-    hipLaunchKernelGGL(k_scatter_zlab, dim3(nblk(Z)), dim3(BT), 0, st, s->zlab.as<int32_t>(), s->zlist.as<uint32_t>(), Z,
-                       d_labels);
-    VCP_HIP(ctx, hipGetLastError());
-  }
+  // labels by original index: kept clusters and the noise pass result, one scatter
+  hipLaunchKernelGGL(k_final_labels, dim3(nblk(n)), dim3(BT), 0, st, newlab, Z > 0 ? s->zlab.as<int32_t>() : nullptr, zrank,
+                     s->bl.as<uint32_t>(), m, n, d_labels);
+  VCP_HIP(ctx, hipGetLastError());
   VCP_HIP(ctx, hipStreamSynchronize(st));
   if (kept_o) *kept_o = (int32_t)kept;
   if (del_o) *del_o = (int32_t)delSum;

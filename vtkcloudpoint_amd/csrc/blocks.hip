@@ -321,14 +321,27 @@ __global__ __launch_bounds__(BT) void k_gather_motor(const double* __restrict__ 
 // 156 k waves serialise on them.)
 // per block: K_b = max local id, Z_b = number of noise points.  One wave per block walks the block's slice of
 // the block-major label list (coalesced) and reduces in registers: no atomics.
-__global__ __launch_bounds__(BT) void k_block_stats(const int32_t* __restrict__ local, const uint32_t* __restrict__ blockstart,
-                                                   int64_t nblocks, uint32_t* __restrict__ kb, uint32_t* __restrict__ zb,
-                                                   uint32_t* __restrict__ kmax_slots) {
-  const int64_t b = (int64_t)blockIdx.x * (BT / 64) + (threadIdx.x >> 6);
-  if (b >= nblocks) return;
-  const int lane = threadIdx.x & 63;
+// NW = 1: one wave per block (blocks of up to BIG_BLOCK positions); NW = 16: one workgroup per block of the host's list of
+// large blocks, like k_block_order below.
+constexpr uint32_t BIG_BLOCK = 1024;
+template <int NW>
+__global__ __launch_bounds__(NW == 1 ? BT : 64 * NW) void k_block_stats(const int32_t* __restrict__ local,
+                                                                       const uint32_t* __restrict__ blockstart,
+                                                                       int64_t nblocks, const uint32_t* __restrict__ biglist,
+                                                                       uint32_t* __restrict__ kb, uint32_t* __restrict__ zb,
+                                                                       uint32_t* __restrict__ kmax_slots) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int64_t b;
+  if (NW == 1) {
+    b = (int64_t)blockIdx.x * (BT / 64) + w;
+    if (b >= nblocks) return;
+  } else {
+    b = biglist[blockIdx.x];
+  }
+  const uint32_t s0 = blockstart[b], s1 = blockstart[b + 1];
+  if (NW == 1 && s1 - s0 > BIG_BLOCK) return;
   uint32_t K = 0, Z = 0;
-  for (uint32_t t = blockstart[b] + lane; t < blockstart[b + 1]; t += 64) {
+  for (uint32_t t = s0 + (NW == 1 ? lane : threadIdx.x); t < s1; t += 64 * NW) {
     const int32_t l = local[t];
     if (l == 0) Z++;
     else K = max(K, (uint32_t)l);
@@ -337,6 +350,19 @@ __global__ __launch_bounds__(BT) void k_block_stats(const int32_t* __restrict__ 
   for (int d = 32; d > 0; d >>= 1) {
     K = max(K, (uint32_t)__shfl_xor((int)K, d, 64));
     Z += (uint32_t)__shfl_xor((int)Z, d, 64);
+  }
+  if (NW > 1) {
+    __shared__ uint32_t sk[NW], sz[NW];
+    if (lane == 0) {
+      sk[w] = K;
+      sz[w] = Z;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int k = 1; k < NW; k++) {
+      K = max(K, sk[k]);
+      Z += sz[k];
+    }
   }
   if (lane == 0) {
     kb[b] = K;
@@ -384,12 +410,13 @@ __global__ __launch_bounds__(BT) void k_cluster_sizes(const int32_t* __restrict_
 //   NW = 16: one workgroup per block of the host's list of large blocks (the heart of a blob can put 10^4 points in
 //           one rectangle; a single wave walking it set the kernel time: 415 us): every wave reads the whole block but
 //           places only the ids congruent to its number, so each cursor has one owner and the order stays stable.
-constexpr uint32_t BIG_BLOCK = 1024;
 template <int NW>
 __global__ __launch_bounds__(NW == 1 ? BT : 64 * NW) void k_block_order(const int32_t* __restrict__ local,
                                                                        const uint32_t* __restrict__ blockstart,
                                                                        int64_t nblocks, const uint32_t* __restrict__ kb,
                                                                        const uint32_t* __restrict__ biglist,
+                                                                       const uint32_t* __restrict__ cstart,
+                                                                       uint32_t* __restrict__ csize,
                                                                        uint32_t* __restrict__ order) {
   constexpr int NG = NW == 1 ? BT / 64 : 1;  // blocks per workgroup
   __shared__ uint32_t cnt[NG][CS_CAP + 1];
@@ -410,6 +437,11 @@ __global__ __launch_bounds__(NW == 1 ? BT : 64 * NW) void k_block_order(const in
   for (uint32_t k = tid; k <= K; k += nthr) cnt[g][k] = 0;
   if (NW == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();
   for (uint32_t t = s0 + tid; t < s1; t += nthr) atomicAdd(&cnt[g][local[t]], 1u);
+  if (NW == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+  {  // the counts of ids 1..K are the cluster sizes CompleteWork3's demotion rule needs (k_keep)
+    const uint32_t c0 = cstart[b];
+    for (uint32_t k = 1 + tid; k <= K; k += nthr) csize[c0 + k - 1] = cnt[g][k];
+  }
   if (NW == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();
   if (w == 0 || NW == 1) {
     // exclusive scan of cnt[0..K] by one wave, 64 entries per trip
@@ -772,7 +804,10 @@ int blocks_finish(vcp_ctx* ctx, const int32_t* d_local, int64_t evals_blocks, in
   const unsigned nbw = (unsigned)((nb + BT / 64 - 1) / (BT / 64));  // one wave per block
   VCP_HIP(ctx, hipMemsetAsync(dmisc, 0, 64 * 4, st));  // [8..40): slots of the largest local id
   VCP_HIP(ctx, hipMemsetAsync(kb + nb, 0, 8, st));  // the scan reads kb[nb]
-  hipLaunchKernelGGL(k_block_stats, dim3(nbw), dim3(BT), 0, st, d_local, blockstart, nb, kb, zb, dmisc + 8);
+  hipLaunchKernelGGL(k_block_stats<1>, dim3(nbw), dim3(BT), 0, st, d_local, blockstart, nb, nullptr, kb, zb, dmisc + 8);
+  if (s->nbig)
+    hipLaunchKernelGGL(k_block_stats<16>, dim3(s->nbig), dim3(1024), 0, st, d_local, blockstart, nb,
+                       s->biglist.as<uint32_t>(), kb, zb, dmisc + 8);
   VCP_TRY(vcp_exclusive_scan_u32(ctx, kb, cstart, nb + 1, dmisc));  // cstart[nb] = total clusters
   uint32_t* hp = reinterpret_cast<uint32_t*>(ctx->pinned);
   VCP_HIP(ctx, hipMemcpyAsync(hp, dmisc, 40 * 4, hipMemcpyDeviceToHost, st));
@@ -787,16 +822,8 @@ int blocks_finish(vcp_ctx* ctx, const int32_t* d_local, int64_t evals_blocks, in
   uint32_t* keep = s->keep.as<uint32_t>();
   uint32_t* keeprank = keep + (totalC + 2);
   uint32_t* victim_of = s->tmp3.as<uint32_t>();
-  VCP_HIP(ctx, hipMemsetAsync(csize, 0, (size_t)(totalC + 2) * 4, st));
-  VCP_HIP(ctx, hipMemsetAsync(keep, 0, (size_t)(totalC + 2) * 4 * 2, st));
-  hipLaunchKernelGGL(k_cluster_sizes, dim3(nbw), dim3(BT), 0, st, d_local, blockstart, nb, kb, cstart, csize);
-  hipLaunchKernelGGL(k_keep, dim3(nblk(nb)), dim3(BT), 0, st, nb, cstart, kb, zb, blockstart, csize, s->small_max, keep,
-                     victim_of, dmisc + 2);
-  VCP_TRY(vcp_exclusive_scan_u32(ctx, keep, keeprank, (int64_t)totalC + 1, dmisc + 1));
-  VCP_TRY(ens(ctx, s->newlab, (size_t)(m + 1) * 4));
-  int32_t* newlab = s->newlab.as<int32_t>();
-  hipLaunchKernelGGL(k_newlab, dim3(nblk(m)), dim3(BT), 0, st, d_local, blk_t, m, cstart, keep, keeprank, newlab);
-  // final order: stable by (block, local id): sort the block-major positions by local id, then by block
+  // final order inside a block: stable by local id -- a per-block counting sort (which also yields the cluster sizes),
+  // or, when some block has more ids than its LDS table, the library-sort form: positions by local id, then by block
   VCP_TRY(ens(ctx, s->order, (size_t)(m + 1) * 4));
   VCP_TRY(ens(ctx, s->tmp0, (size_t)(m + 1) * 8));
   VCP_TRY(ens(ctx, s->tmp1, (size_t)(m + 1) * 8));
@@ -808,18 +835,28 @@ int blocks_finish(vcp_ctx* ctx, const int32_t* d_local, int64_t evals_blocks, in
   uint32_t* k2 = v1o + (m + 1);
   uint32_t* order = s->order.as<uint32_t>();
   const bool order_by_sort = getenv("VCP_BLOCKS_ORDER_SORT") != nullptr;  // test switch: the library-sort form
+  VCP_HIP(ctx, hipMemsetAsync(keep, 0, (size_t)(totalC + 2) * 4 * 2, st));
   if (m > 0 && maxK <= (uint32_t)CS_CAP && !order_by_sort) {
-    hipLaunchKernelGGL(k_block_order<1>, dim3(nbw), dim3(BT), 0, st, d_local, blockstart, nb, kb, nullptr, order);
+    hipLaunchKernelGGL(k_block_order<1>, dim3(nbw), dim3(BT), 0, st, d_local, blockstart, nb, kb, nullptr, cstart, csize,
+                       order);
     if (s->nbig)
       hipLaunchKernelGGL(k_block_order<16>, dim3(s->nbig), dim3(1024), 0, st, d_local, blockstart, nb, kb,
-                         s->biglist.as<uint32_t>(), order);
+                         s->biglist.as<uint32_t>(), cstart, csize, order);
   } else if (m > 0) {
+    VCP_HIP(ctx, hipMemsetAsync(csize, 0, (size_t)(totalC + 2) * 4, st));
+    hipLaunchKernelGGL(k_cluster_sizes, dim3(nbw), dim3(BT), 0, st, d_local, blockstart, nb, kb, cstart, csize);
     hipLaunchKernelGGL(k_iota, dim3(nblk(m)), dim3(BT), 0, st, iota, m);
     VCP_HIP(ctx, hipMemcpyAsync(k1, d_local, (size_t)m * 4, hipMemcpyDeviceToDevice, st));
     VCP_TRY(sort_pairs(ctx, s, k1, k1o, iota, v1o, (size_t)m, bits_for(maxK)));
     hipLaunchKernelGGL(k_gather_u32, dim3(nblk(m)), dim3(BT), 0, st, blk_t, v1o, m, k2);
     VCP_TRY(sort_pairs(ctx, s, k2, k1o, v1o, order, (size_t)m, bits_for((uint64_t)nb)));
   }
+  hipLaunchKernelGGL(k_keep, dim3(nblk(nb)), dim3(BT), 0, st, nb, cstart, kb, zb, blockstart, csize, s->small_max, keep,
+                     victim_of, dmisc + 2);
+  VCP_TRY(vcp_exclusive_scan_u32(ctx, keep, keeprank, (int64_t)totalC + 1, dmisc + 1));
+  VCP_TRY(ens(ctx, s->newlab, (size_t)(m + 1) * 4));
+  int32_t* newlab = s->newlab.as<int32_t>();
+  hipLaunchKernelGGL(k_newlab, dim3(nblk(m)), dim3(BT), 0, st, d_local, blk_t, m, cstart, keep, keeprank, newlab);
   hipLaunchKernelGGL(k_victims, dim3(nblk(nb)), dim3(BT), 0, st, nb, victim_of, blockstart, order, newlab);
   // zero list (FrmMain.cs:1510-1515) and merge order
   VCP_TRY(ens(ctx, s->zflag, (size_t)(m + 2) * 4));

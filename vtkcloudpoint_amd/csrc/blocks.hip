@@ -34,7 +34,7 @@ struct BlocksState {
   const double* motor_ptr = nullptr;  // the cloud on the device: our upload (host entry points) or the caller's array
   DevBuf motor, pkey, orand, raw, blockof, bl, motor_bm, blockstart, gtwice, gnclus, tmp0, tmp1, tmp2, tmp3, sorttmp,
       blk_t, csize, cstart, kb, zb, keep, order, newlab, zflag, zlist, zcoords, zlab, misc;
-  std::vector<uint32_t> h_blockstart;
+  std::vector<uint32_t> h_blockstart, h_big;
   DevBuf biglist;     // blocks of more than BIG_BLOCK points (k_block_order<16>), found on the host at begin
   uint32_t nbig = 0;
   bool ready = false;
@@ -742,14 +742,14 @@ int blocks_begin(vcp_ctx* ctx, const double* d_motor_in, bool from_host, const d
   s->m = s->h_blockstart[(size_t)s->nblocks];
   if (m_o) *m_o = s->m;
   {
-    std::vector<uint32_t> big;
+    std::vector<uint32_t>& big = s->h_big;  // a member: the copy below is asynchronous
+    big.clear();
     for (int64_t b = 0; b < s->nblocks; b++)
       if (s->h_blockstart[(size_t)b + 1] - s->h_blockstart[(size_t)b] > BIG_BLOCK) big.push_back((uint32_t)b);
     s->nbig = (uint32_t)big.size();
     if (s->nbig) {
       VCP_TRY(ens(ctx, s->biglist, big.size() * 4));
       VCP_HIP(ctx, hipMemcpyAsync(s->biglist.p, big.data(), big.size() * 4, hipMemcpyHostToDevice, st));
-      VCP_HIP(ctx, hipStreamSynchronize(st));  // `big` is a local buffer
     }
   }
   VCP_TRY(ens(ctx, s->gtwice, (size_t)nb1 * 4));

@@ -1,0 +1,122 @@
+"""Test tooling (not collected by pytest; lives under tests/ because it drives the oracle).  Randomised parity sweep on
+the GPU box: libvcp (through the C-ABI) against the order-free CPU oracle on clouds no
+fixed test has -- sizes from one point to a few million, uniform / clustered / lattice / duplicate-heavy / collinear
+shapes, far outliers, non-finite coordinates, every metric, isClassed inputs, cf presets -- plus the block pipeline.
+usage: python tests/fuzz_parity.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import binding as O  # noqa: E402  (test tooling: the oracle is the checker)
+from vtkcloudpoint_amd import _native as N  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+rng = np.random.default_rng(seed)
+ctx = N.Context(0)
+t0 = time.time()
+done = {"dbscan": 0, "blocks": 0}
+
+
+KIND = [0]
+
+
+def cloud(n, dim):
+    kind = int(rng.integers(0, 7))
+    KIND[0] = kind
+    ext = float(rng.choice([1.0, 10.0, 300.0, 1e4]))
+    if kind == 0:
+        c = rng.uniform(0, ext, (n, dim))
+    elif kind == 1:  # blobs on a sparse background
+        k = max(1, n // int(rng.integers(50, 5000)))
+        cen = rng.uniform(0, ext, (k, dim))
+        c = cen[rng.integers(0, k, n)] + rng.normal(0, ext * float(rng.choice([1e-3, 1e-2])), (n, dim))
+        bg = rng.random(n) < 0.3
+        c[bg] = rng.uniform(0, ext, (int(bg.sum()), dim))
+    elif kind == 2:  # lattice: exact ties, duplicates
+        side = max(2, int(rng.integers(2, 2000)))
+        c = rng.integers(0, side, (n, dim)).astype(np.float64) * float(rng.choice([0.25, 1.0, 3.0]))
+    elif kind == 3:  # heavy duplicates
+        k = max(1, n // int(rng.integers(2, 200)))
+        c = rng.uniform(0, ext, (k, dim))[rng.integers(0, k, n)]
+    elif kind == 4:  # collinear / degenerate axis
+        c = rng.uniform(0, ext, (n, dim))
+        c[:, int(rng.integers(0, dim))] = float(rng.uniform(-5, 5))
+    elif kind == 5:  # far outliers coarsen / trim the grid
+        c = rng.normal(0, 1.0, (n, dim))
+        m = max(1, n // 1000)
+        c[rng.integers(0, n, m)] *= float(rng.choice([1e3, 1e6, 1e9]))
+    else:  # quantised to 2^-10 like the benchmark clouds, off the origin
+        c = np.round(rng.uniform(0, ext, (n, dim)) * 1024) / 1024 + float(rng.choice([0.0, 12345.5, -7e5]))
+    if rng.random() < 0.1 and n > 3:
+        bad = rng.integers(0, n, max(1, n // 500))
+        c[bad, int(rng.integers(0, dim))] = float(rng.choice([np.nan, np.inf, -np.inf]))
+    return np.ascontiguousarray(c)
+
+
+while time.time() - t0 < budget:
+    n = int(10 ** rng.uniform(0, 6.3))
+    metric = int(rng.integers(0, 3))
+    dim = 3 if metric == 2 else int(rng.integers(2, 4))
+    c = cloud(n, dim)
+    fin = c[np.isfinite(c).all(axis=1)]
+    span = float(np.ptp(fin[:, 0])) if len(fin) else 1.0
+    # eps so that a typical point has from none to a few dozen neighbours
+    dens = n / max(span, 1e-9) ** (3 if metric == 2 else 2)
+    eps = float((rng.uniform(0.2, 30) / max(dens, 1e-12)) ** (1.0 / (3 if metric == 2 else 2)))
+    if rng.random() < 0.15:
+        eps = float(rng.choice([0.0, 0.25, 1.0, 3.0]))
+    if eps == 0.0 and n > 30000:  # the CPU oracle's grid degenerates at eps = 0 (quadratic): small clouds only
+        c = np.ascontiguousarray(c[:30000])
+        n = len(c)
+    mp = int(rng.choice([1, 2, 3, 5, 7, 10, 16, 17, 40]))
+    cf = int(rng.integers(0, 5))
+    if rng.random() < 0.25:
+        cls = (rng.random(n) < 0.1).astype(np.uint8)
+        lab0 = (rng.integers(1, 4, n) * cls).astype(np.int32)
+    else:
+        cls, lab0 = None, None
+    print("case n=%d dim=%d metric=%d eps=%.6g mp=%d cf=%d cls=%d kind=%d" % (n, dim, metric, eps, mp, cf, cls is not None, KIND[0]),
+          end="", flush=True)
+    t1 = time.time()
+    g = ctx.dbscan(c, eps, mp, metric, cf, cls, lab0)
+    t2 = time.time()
+    print(" gpu %.3fs" % (t2 - t1), end="", flush=True)
+    o = O.dbscan(c, eps, mp, metric, cf, cls, lab0)
+    print(" cpu %.2fs" % (time.time() - t2), flush=True)
+    ok = (np.array_equal(g["labels"], o["labels"]) and np.array_equal(g["is_classed"], o["classed"])
+          and np.array_equal(g["is_core"], o["is_key"]) and g["cf"] == o["cf"] and g["evals"] == o["evals"])
+    if not ok:
+        np.savez("gpurun_out/fuzz_fail_dbscan.npz", c=c, eps=eps, mp=mp, metric=metric, cf=cf,
+                 cls=np.zeros(0) if cls is None else cls, lab0=np.zeros(0) if lab0 is None else lab0)
+        print("MISMATCH dbscan n=%d dim=%d metric=%d eps=%r mp=%d cf=%d cls=%s" % (n, dim, metric, eps, mp, cf, cls is not None),
+              flush=True)
+        sys.exit(1)
+    done["dbscan"] += 1
+    if rng.random() < 0.3 and n >= 2 and np.isfinite(c).all():
+        m2 = np.ascontiguousarray(c[:, :2])
+        pic = int(rng.choice([1, 3, 20, 200, 5000]))
+        try:
+            ob = O.block_pipeline(m2, eps, mp, pic, 3)
+        except O.OracleError as e:
+            try:
+                ctx.dbscan_blocks(m2, eps, mp, pic, 3)
+                print("MISSING ERROR blocks n=%d oracle code %d" % (n, e.code), flush=True)
+                sys.exit(1)
+            except N.VcpError:
+                continue
+        gb = ctx.dbscan_blocks(m2, eps, mp, pic, 3)
+        okb = (np.array_equal(gb["labels"], ob["labels"]) and np.array_equal(gb["order"], ob["order"])
+               and np.array_equal(gb["block_of"], ob["block_of"]) and gb["kept"] == ob["kept"]
+               and gb["cluster_amount"] == ob["cluster_amount"] and gb["evals"] == ob["evals"])
+        if not okb:
+            np.savez("gpurun_out/fuzz_fail_blocks.npz", m=m2, eps=eps, mp=mp, pic=pic)
+            print("MISMATCH blocks n=%d eps=%r mp=%d pic=%d" % (n, eps, mp, pic), flush=True)
+            sys.exit(1)
+        done["blocks"] += 1
+    if (done["dbscan"] % 50) == 0:
+        print("%.0f s: %d dbscan, %d block pipelines agree" % (time.time() - t0, done["dbscan"], done["blocks"]), flush=True)
+print("OK: %d dbscan calls and %d block pipelines bit-exact against the oracle (seed %d)" % (done["dbscan"], done["blocks"], seed))

@@ -1679,13 +1679,19 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   // inside it, repeatedly: a handful of far outliers then end up in the edge cells instead of coarsening the
   // grid for the whole cloud.
   {
+    // (the cell edge is at least range / 2^20 -- eps = 0 asks for exact duplicates only -- and the trimming has to see
+    // that edge, not a zero one: with eps = 0 and a few far outliers the untrimmed range put 700 k points into ONE cell,
+    // 1.2 s instead of 1 ms)
     auto cells_needed = [&](const double* lo, const double* hi) {
+      double r = 0.0;
+      for (int a = 0; a < GD; a++) r = std::fmax(r, hi[a] - lo[a]);
+      const double cw = std::fmax(cellw, r / 1048575.0);
       double c = 1.0;
-      for (int a = 0; a < GD; a++) c *= std::floor((hi[a] - lo[a]) / cellw) + 1.0;
+      for (int a = 0; a < GD; a++) c *= std::floor((hi[a] - lo[a]) / cw) + 1.0;
       return c;
     };
     double lo[3] = {h[0], h[1], h[2]}, hi[3] = {h[3], h[4], h[5]};
-    for (int it = 0; it < 8 && cellw > 0.0 && std::isfinite(cellw) && !(cells_needed(lo, hi) <= (double)budget); it++) {
+    for (int it = 0; it < 8 && cellw >= 0.0 && std::isfinite(cellw) && !(cells_needed(lo, hi) <= (double)budget); it++) {
       Range3 R;
       for (int a = 0; a < 3; a++) {
         R.lo[a] = lo[a];

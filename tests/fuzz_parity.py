@@ -63,10 +63,18 @@ while time.time() - t0 < budget:
     dim = 3 if metric == 2 else int(rng.integers(2, 4))
     c = cloud(n, dim)
     fin = c[np.isfinite(c).all(axis=1)]
-    span = float(np.ptp(fin[:, 0])) if len(fin) else 1.0
-    # eps so that a typical point has from none to a few dozen neighbours
-    dens = n / max(span, 1e-9) ** (3 if metric == 2 else 2)
-    eps = float((rng.uniform(0.2, 30) / max(dens, 1e-12)) ** (1.0 / (3 if metric == 2 else 2)))
+    gd = 3 if metric == 2 else 2
+    # robust extent per axis (outliers and degenerate axes must not fool the density estimate: the CPU oracle is
+    # quadratic in the neighbourhood size); eps so that a typical point has from none to a few dozen neighbours
+    if len(fin) > 10:
+        q = np.percentile(fin[:, :gd], [2, 98], axis=0)
+        spans = np.maximum(q[1] - q[0], 0.0)
+    else:
+        spans = np.ones(gd)
+    live = spans[spans > 0]
+    vol = float(np.prod(live)) if len(live) else 1.0
+    deff = max(len(live), 1)
+    eps = float((rng.uniform(0.2, 30) * vol / max(n, 1)) ** (1.0 / deff))
     if rng.random() < 0.15:
         eps = float(rng.choice([0.0, 0.25, 1.0, 3.0]))
     if eps == 0.0 and n > 30000:  # the CPU oracle's grid degenerates at eps = 0 (quadratic): small clouds only

@@ -230,3 +230,32 @@ def test_lattice_every_neighbour_exactly_on_eps(vcp_ctx, oracle, metric, dim):
             g = vcp_ctx.dbscan(cc, step, mp, metric)
             _same(g, o, "shift %g mp %d" % (shift, mp))
             assert np.array_equal(g["is_core"], o["is_key"])
+
+
+def test_eps_zero_with_far_outliers_is_duplicate_grouping_and_fast(vcp_ctx, oracle):
+    """eps = 0: a point's neighbours are its exact duplicates, so clusters are the duplicate groups of >= minPts points,
+    numbered by first occurrence.  With a few far outliers the grid used to be cut over the untrimmed range (the trimming
+    tested a zero cell edge): 700 k points in one cell, 1.2 s.  Checked against numpy at that size, with a time bound,
+    and against the oracle on a prefix it can afford."""
+    import time
+    rng = np.random.default_rng(8)
+    n = 700_000
+    c = np.round(rng.normal(0, 1.0, (n, 2)) * 64) / 64        # duplicates: ~40 k distinct positions in the bulk
+    c[rng.integers(0, n, 700)] *= 1e6
+    mp = 3
+    vcp_ctx.dbscan(c[:1000], 0.0, mp, N.L1_2D)                 # warm-up (allocation)
+    t = time.perf_counter()
+    g = vcp_ctx.dbscan(c, 0.0, mp, N.L1_2D)
+    dt = time.perf_counter() - t
+    assert dt < 0.25, "eps = 0 call took %.3f s" % dt          # host-buffer entry point: ~10 ms of it is PCIe
+    _, inv, cnt = np.unique(c, axis=0, return_inverse=True, return_counts=True)
+    inv = inv.reshape(-1)
+    clustered = cnt[inv] >= mp
+    first = np.full(len(cnt), n, np.int64)
+    np.minimum.at(first, inv, np.arange(n))
+    seeds = np.sort(first[cnt >= mp])
+    want = np.where(clustered, np.searchsorted(seeds, first[inv]) + 1, 0).astype(np.int32)
+    assert np.array_equal(g["labels"], want) and g["cf"] == len(seeds)
+    assert np.array_equal(g["is_core"].astype(bool), clustered)
+    o = oracle.dbscan(c[:20000], 0.0, mp, oracle.L1_2D)
+    _same(vcp_ctx.dbscan(c[:20000], 0.0, mp, N.L1_2D), o)

@@ -57,11 +57,63 @@ def cloud(n, dim):
     return np.ascontiguousarray(c)
 
 
+def nn_case():
+    """nearest neighbour of ICP (squared distances, lowest index on ties) and of the matching (sqrt distances) through
+    every form: scalar cache (<= 512 model points), grid, and the full scan of non-finite models"""
+    nm = int(10 ** rng.uniform(0, 4.6))
+    nd = int(min(10 ** rng.uniform(0, 4.6), 2e8 / max(nm, 1)))
+    nd = max(nd, 1)
+    kind = int(rng.integers(0, 5))
+    if kind == 0:
+        model, data = rng.uniform(0, 50, (nm, 3)), rng.uniform(-10, 60, (nd, 3))
+    elif kind == 1:  # lattices: thousands of exact ties
+        model = rng.integers(0, 12, (nm, 3)).astype(np.float64) * 0.5
+        data = rng.integers(-4, 30, (nd, 3)).astype(np.float64) * 0.25
+    elif kind == 2:  # clustered model (centroids of fragments), data near it
+        k = max(1, nm // 100)
+        cen = rng.uniform(0, 200, (k, 3))
+        model = cen[rng.integers(0, k, nm)] + rng.normal(0, 0.5, (nm, 3))
+        data = model[rng.integers(0, nm, nd)] + rng.normal(0, 0.05, (nd, 3))
+    elif kind == 3:  # planar / collinear
+        model, data = rng.uniform(0, 50, (nm, 3)), rng.uniform(0, 50, (nd, 3))
+        model[:, 2] = 3.0
+        if rng.random() < 0.5:
+            model[:, 1] = -1.0
+    else:  # data far away from the model
+        model, data = rng.uniform(0, 5, (nm, 3)), rng.uniform(0, 5, (nd, 3)) + float(rng.choice([1e2, 1e4, -1e3]))
+    if rng.random() < 0.1:
+        model[int(rng.integers(0, nm)), int(rng.integers(0, 3))] = float(rng.choice([np.nan, np.inf]))
+    sums, nn = ctx.icp_sums(model, data)
+    want = O.find_closest(model, data)
+    if not np.array_equal(nn, want):
+        np.savez("gpurun_out/fuzz_fail_nn.npz", model=model, data=data)
+        print("MISMATCH nn nm=%d nd=%d kind=%d" % (nm, nd, kind), flush=True)
+        sys.exit(1)
+    if np.isfinite(model).all():
+        M = np.eye(4)
+        M[:3, 3] = rng.normal(0, 0.1, 3)
+        md = float(rng.choice([0.1, 1.0, 10.0]))
+        gm = ctx.match(data[:20000], model, M, md)
+        om = O.match(data[:20000], model, M.reshape(16), md)
+        if not (np.array_equal(gm["nearest"], om["nearest"]) and np.array_equal(gm["is_matched"], om["is_matched"])
+                and np.array_equal(gm["matched_xyz"], om["matched_xyz"]) and gm["count"] == om["count"]):
+            np.savez("gpurun_out/fuzz_fail_match.npz", model=model, data=data, M=M, md=md)
+            print("MISMATCH match K=%d T=%d kind=%d" % (min(nd, 20000), nm, kind), flush=True)
+            sys.exit(1)
+    done["nn"] = done.get("nn", 0) + 1
+
+
 while time.time() - t0 < budget:
+    if rng.random() < 0.25:
+        nn_case()
+        continue
     n = int(10 ** rng.uniform(0, 6.3))
     metric = int(rng.integers(0, 3))
     dim = 3 if metric == 2 else int(rng.integers(2, 4))
     c = cloud(n, dim)
+    if KIND[0] == 5 and n > 50000:  # the CPU oracle grids the full bounding box: with far outliers its cells hold the whole
+        c = np.ascontiguousarray(c[:50000])  # bulk and it turns quadratic -- small clouds only for this shape
+        n = len(c)
     fin = c[np.isfinite(c).all(axis=1)]
     gd = 3 if metric == 2 else 2
     # robust extent per axis (outliers and degenerate axes must not fool the density estimate: the CPU oracle is
@@ -127,4 +179,5 @@ while time.time() - t0 < budget:
         done["blocks"] += 1
     if (done["dbscan"] % 50) == 0:
         print("%.0f s: %d dbscan, %d block pipelines agree" % (time.time() - t0, done["dbscan"], done["blocks"]), flush=True)
-print("OK: %d dbscan calls and %d block pipelines bit-exact against the oracle (seed %d)" % (done["dbscan"], done["blocks"], seed))
+print("OK: %d dbscan calls, %d block pipelines and %d nearest-neighbour / matching cases bit-exact against the oracle (seed %d)"
+      % (done["dbscan"], done["blocks"], done.get("nn", 0), seed))

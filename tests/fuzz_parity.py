@@ -127,8 +127,8 @@ while time.time() - t0 < budget:
     vol = float(np.prod(live)) if len(live) else 1.0
     deff = max(len(live), 1)
     eps = float((rng.uniform(0.2, 30) * vol / max(n, 1)) ** (1.0 / deff))
-    if rng.random() < 0.15:
-        eps = float(rng.choice([0.0, 0.25, 1.0, 3.0]))
+    if rng.random() < 0.15 and n <= 20000:  # round thresholds (exact ties on the lattices); small clouds only: on a
+        eps = float(rng.choice([0.0, 0.25, 1.0, 3.0]))  # cloud that fits inside eps the CPU oracle is quadratic
     if eps == 0.0 and n > 30000:  # the CPU oracle's grid degenerates at eps = 0 (quadratic): small clouds only
         c = np.ascontiguousarray(c[:30000])
         n = len(c)

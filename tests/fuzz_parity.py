@@ -103,9 +103,59 @@ def nn_case():
     done["nn"] = done.get("nn", 0) + 1
 
 
+def tools_case():
+    """centroids (plain and ptsCount-weighted), centroid merge, and the keyed block pipeline (partition on X,Y, DBSCAN on
+    motor) on random clouds"""
+    n = int(10 ** rng.uniform(0.5, 5.3))
+    K = int(rng.integers(1, max(2, min(n, 3000))))
+    xyz = rng.uniform(-100, 100, (n, 3)) if rng.random() < 0.7 else rng.integers(-9, 9, (n, 3)).astype(np.float64)
+    motor = rng.uniform(-10, 10, (n, 2))
+    lab = rng.integers(0, K + 1, n).astype(np.int32)
+    g3, g2, gc = ctx.centroids(xyz, motor, lab, K)
+    o3, o2, oc = O.centroids(xyz, motor, lab, K)
+    ok = np.array_equal(gc, oc)
+    full = oc > 0
+    ok = ok and np.allclose(g3[full], o3[full], rtol=1e-12, atol=1e-9) and np.allclose(g2[full], o2[full], rtol=1e-12, atol=1e-10)
+    ok = ok and np.isnan(g3[~full]).all()
+    grp = rng.integers(0, K, n).astype(np.int32)
+    cid = rng.integers(0, 3, n).astype(np.int32)
+    pc = rng.integers(1, 6, n).astype(np.int32)
+    ign = bool(rng.integers(0, 2))
+    w3, wi = ctx.centroids_weighted(xyz, grp, cid, pc, K, ign)
+    v3, vi = O.fixed_centroids(xyz, grp, cid, pc, K, ign)
+    has = vi > 0
+    ok = ok and np.array_equal(wi, vi) and np.allclose(w3[has], v3[has], rtol=1e-12, atol=1e-9)
+    cen = np.round(rng.uniform(0, 30, (min(K, 2000), 2)) * 8) / 8
+    ids = np.arange(1, len(cen) + 1, dtype=np.int32)
+    thr = float(rng.choice([0.25, 0.5, 1.0]))
+    gm, gmc = ctx.merge_centroids(cen, ids, thr)
+    om, omc = O.merge_ids(cen, ids, thr)
+    ok = ok and np.array_equal(gm, om) and gmc == omc
+    if n >= 2:
+        key = np.round(rng.uniform(0, 20, (n, 2)) * 64) / 64
+        mot = np.round(rng.uniform(0, 20, (n, 2)) * 64) / 64 if rng.random() < 0.5 else key + 0.0
+        eps, mp, pic = float(rng.choice([0.125, 0.3, 0.7])), int(rng.integers(1, 8)), int(rng.choice([5, 50, 400]))
+        try:
+            ob = O.block_pipeline(mot, eps, mp, pic, 3, key_xy=key)
+        except O.OracleError:
+            ob = None
+        if ob is not None:
+            gb = ctx.dbscan_blocks(mot, eps, mp, pic, 3, key_xy=key)
+            ok = ok and np.array_equal(gb["labels"], ob["labels"]) and np.array_equal(gb["order"], ob["order"]) \
+                and gb["cluster_amount"] == ob["cluster_amount"] and gb["evals"] == ob["evals"]
+    if not ok:
+        print("MISMATCH tools n=%d K=%d" % (n, K), flush=True)
+        sys.exit(1)
+    done["tools"] = done.get("tools", 0) + 1
+
+
 while time.time() - t0 < budget:
-    if rng.random() < 0.25:
+    u = rng.random()
+    if u < 0.2:
         nn_case()
+        continue
+    if u < 0.3:
+        tools_case()
         continue
     n = int(10 ** rng.uniform(0, 6.3))
     metric = int(rng.integers(0, 3))
@@ -179,5 +229,5 @@ while time.time() - t0 < budget:
         done["blocks"] += 1
     if (done["dbscan"] % 50) == 0:
         print("%.0f s: %d dbscan, %d block pipelines agree" % (time.time() - t0, done["dbscan"], done["blocks"]), flush=True)
-print("OK: %d dbscan calls, %d block pipelines and %d nearest-neighbour / matching cases bit-exact against the oracle (seed %d)"
-      % (done["dbscan"], done["blocks"], done.get("nn", 0), seed))
+print("OK: %d dbscan calls, %d block pipelines, %d nearest-neighbour / matching cases bit-exact and %d centroid / merge / keyed-"
+      "pipeline cases against the oracle (seed %d)" % (done["dbscan"], done["blocks"], done.get("nn", 0), done.get("tools", 0), seed))

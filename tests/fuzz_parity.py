@@ -107,7 +107,8 @@ def tools_case():
     """centroids (plain and ptsCount-weighted), centroid merge, and the keyed block pipeline (partition on X,Y, DBSCAN on
     motor) on random clouds"""
     n = int(10 ** rng.uniform(0.5, 5.3))
-    K = int(rng.integers(1, max(2, min(n, 3000))))
+    K = int(rng.integers(1, max(2, min(n, 3000) + 1)))
+    K = min(K, n)
     xyz = rng.uniform(-100, 100, (n, 3)) if rng.random() < 0.7 else rng.integers(-9, 9, (n, 3)).astype(np.float64)
     motor = rng.uniform(-10, 10, (n, 2))
     lab = rng.integers(0, K + 1, n).astype(np.int32)
@@ -118,6 +119,7 @@ def tools_case():
     ok = ok and np.allclose(g3[full], o3[full], rtol=1e-12, atol=1e-9) and np.allclose(g2[full], o2[full], rtol=1e-12, atol=1e-10)
     ok = ok and np.isnan(g3[~full]).all()
     grp = rng.integers(0, K, n).astype(np.int32)
+    grp[:K] = np.arange(K)  # no empty list: clusList[i].li[0] throws in the C# (VCP_ERR_INDEX here, covered by the tests)
     cid = rng.integers(0, 3, n).astype(np.int32)
     pc = rng.integers(1, 6, n).astype(np.int32)
     ign = bool(rng.integers(0, 2))

@@ -118,8 +118,8 @@ def tools_case():
     full = oc > 0
     ok = ok and np.allclose(g3[full], o3[full], rtol=1e-12, atol=1e-9) and np.allclose(g2[full], o2[full], rtol=1e-12, atol=1e-10)
     ok = ok and np.isnan(g3[~full]).all()
-    grp = rng.integers(0, K, n).astype(np.int32)
-    grp[:K] = np.arange(K)  # no empty list: clusList[i].li[0] throws in the C# (VCP_ERR_INDEX here, covered by the tests)
+    grp = rng.integers(0, K + 1, n).astype(np.int32)  # 1..K, 0 = in no list
+    grp[:K] = np.arange(1, K + 1)  # no empty list: clusList[i].li[0] throws in the C# (VCP_ERR_INDEX here, covered by the tests)
     cid = rng.integers(0, 3, n).astype(np.int32)
     pc = rng.integers(1, 6, n).astype(np.int32)
     ign = bool(rng.integers(0, 2))

@@ -259,3 +259,22 @@ def test_eps_zero_with_far_outliers_is_duplicate_grouping_and_fast(vcp_ctx, orac
     assert np.array_equal(g["is_core"].astype(bool), clustered)
     o = oracle.dbscan(c[:20000], 0.0, mp, oracle.L1_2D)
     _same(vcp_ctx.dbscan(c[:20000], 0.0, mp, N.L1_2D), o)
+
+
+@pytest.mark.parametrize("metric", [N.L1_2D, N.L2_2D, N.L2_3D])
+def test_dense_cloud_takes_the_chunk_skipping_union(vcp_ctx, oracle, metric):
+    """More than 16 points per grid cell on average: the union scan skips chunks of 64 positions that already hang under
+    the point's own root.  Several clusters that touch (so that trees meet late), gaps, duplicates; with a minPts above
+    the list limit too (the scan is then the only union step)."""
+    rng = np.random.default_rng(600 + metric)
+    dim = 3 if metric == N.L2_3D else 2
+    parts = [rng.uniform(0, 1.0, (25_000, dim)), rng.uniform(0, 1.0, (25_000, dim)) + 1.2,
+             rng.normal(0.5, 0.02, (15_000, dim)) + np.array([1.6, 0.0, 0.0][:dim]), rng.uniform(0, 2.2, (3_000, dim))]
+    c = np.round(np.concatenate(parts) * 512) / 512
+    c = c[rng.permutation(len(c))]
+    eps = 0.12 if dim == 2 else 0.3
+    for mp in (5, 20):
+        o = oracle.dbscan(c, eps, mp, metric)
+        g = vcp_ctx.dbscan(c, eps, mp, metric)
+        _same(g, o, "mp %d" % mp)
+        assert np.array_equal(g["is_core"], o["is_key"])

@@ -1014,6 +1014,29 @@ __global__ __launch_bounds__(TPB) void k_flatten0(uint32_t* __restrict__ parent,
   __hip_atomic_store(&parent[p], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
+// Dense clouds (eps well above the point spacing: hundreds of candidates per row).  After phases 1-2 nearly every
+// candidate of an expanding point already hangs under the point's own root, and phase 3 would still read one parent
+// word per candidate: O(n x candidates), e.g. 0.42 s for 445 k points that all lie within eps of each other.  One word
+// per chunk of 64 consecutive positions says whether all its expanding points carry the SAME parent word (or whether it
+// has none): phase 3 then skips such a chunk with one load when that word is its own root.  Trees only ever merge, so a
+// chunk that pointed at my root when the summary was taken is still in my tree.  Used when the grid averages more than
+// DENSE_PER_CELL points per cell; sparse clouds (the benchmark clouds: 0.1 per cell) keep the plain loop.
+constexpr uint32_t CHUNK_MIXED = 0xFFFFFFFEu;
+constexpr int DENSE_PER_CELL = 16;
+__global__ __launch_bounds__(TPB) void k_chunkroot(const uint32_t* __restrict__ parent, const uint32_t* __restrict__ cellstart,
+                                                  uint32_t ncells, uint32_t* __restrict__ chunkroot) {
+  const uint32_t nin = cellstart[ncells];
+  const int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  const uint32_t x = p < nin ? parent[p] : NONE;  // NONE = not expanding
+  const unsigned long long have = __ballot(x != NONE);
+  uint32_t out = NONE;  // no expanding point in the chunk
+  if (have) {
+    const uint32_t r = (uint32_t)__shfl((int)x, __ffsll((long long)have) - 1, 64);
+    out = __ballot(x != NONE && x != r) ? CHUNK_MIXED : r;
+  }
+  if ((threadIdx.x & 63) == 0) chunkroot[p >> 6] = out;
+}
+
 // Phase 3: all remaining core-core edges.  PRE (2-D, after phases 1-2): the candidate's parent word is read
 // FIRST -- NONE = not expanding, my own cached root = already in my tree (the common case inside a cluster) --
 // and only candidates in a different tree pay for the coordinate load and the binary64 test.  Confirmed edges
@@ -1045,11 +1068,12 @@ __global__ __launch_bounds__(TPB) void k_flatten0(uint32_t* __restrict__ parent,
 
 // (Staging the parent words of a workgroup's three candidate rows in LDS, as the core count does with coordinates, was
 // measured: 282 us against 258 us -- the per-workgroup range reduction and barriers cost more than the L1 accesses saved.)
-template <int GD, int METRIC, bool GROUPED, bool PRE>
+template <int GD, int METRIC, bool GROUPED, bool PRE, bool DENSE = false>
 __global__ __launch_bounds__(TPB) void k_union(ExactSrc xs, GridP g, double thr,
                                               const uint32_t* __restrict__ cellstart,
                                               const int32_t* __restrict__ sgroup, uint32_t* __restrict__ parent,
-                                              WorkList wlE, const float* __restrict__ sorted32, Screen sc) {
+                                              WorkList wlE, const float* __restrict__ sorted32, Screen sc,
+                                              const uint32_t* __restrict__ chunkroot = nullptr) {
   const uint32_t p = wl_fetch(wlE);
   if (p == NONE) return;
   constexpr int NR = GD == 3 ? 9 : 3;
@@ -1069,7 +1093,21 @@ __global__ __launch_bounds__(TPB) void k_union(ExactSrc xs, GridP g, double thr,
   for (int r = 0; r < NR; r++) {
     const uint32_t s = rs[r];
     const uint32_t e = min(re[r], me);  // every undirected edge is handled by its larger endpoint
+    uint32_t last_c = NONE;
     for (uint32_t j0 = s; j0 < e; j0 += UNR) {
+      if (DENSE) {  // entering a chunk of 64 positions that lies wholly in the row: skip it if it is all mine (or empty)
+        const uint32_t cj = j0 >> 6;
+        if (cj != last_c) {
+          last_c = cj;
+          if ((cj << 6) >= s && ((cj + 1u) << 6) <= e) {
+            const uint32_t cr = chunkroot[cj];
+            if (cr == NONE || cr == rp) {
+              j0 = ((cj + 1u) << 6) - UNR;  // (positions of this chunk before j0 belonged to the previous trip)
+              continue;
+            }
+          }
+        }
+      }
       uint32_t pj[UNR];
       float cf[UNR][3];
 #pragma unroll
@@ -1915,7 +1953,14 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
                        flags, parent, wlE, sorted32, sc);
     hipLaunchKernelGGL(k_flatten0<false>, dim3(nbl), dim3(TPB), 0, st, parent, wlE, flags, no);
   }
-  if (pre)
+  const bool dense = pre && (uint64_t)n > (uint64_t)DENSE_PER_CELL * g.ncells;
+  if (dense) {
+    VCP_TRY(vcp_ensure(ctx, ctx->b_aux0, ((size_t)nb * (TPB / 64) + 2) * 4));  // one word per wave of k_chunkroot
+    uint32_t* chunkroot = ctx->b_aux0.as<uint32_t>();
+    hipLaunchKernelGGL(k_chunkroot, dim3(nb), dim3(TPB), 0, st, parent, cellcnt, g.ncells, chunkroot);
+    hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED, true, true>), dim3(nbl), dim3(TPB), 0, st, xs, g, thr, cellcnt, sgroup,
+                       parent, wlE, sorted32, sc, chunkroot);
+  } else if (pre)
     hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED, true>), dim3(nbl), dim3(TPB), 0, st, xs, g, thr, cellcnt, sgroup,
                        parent, wlE, sorted32, sc);
   else

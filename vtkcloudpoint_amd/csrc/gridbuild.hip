@@ -24,6 +24,8 @@
 // The order of points inside a cell follows the LDS atomics and may differ from run to run; every result of the engine
 // is order-free by construction (numbering by smallest LIST position, border rule by max id), which
 // tests/test_determinism_gpu.py re-checks on the GPU.
+#include <algorithm>
+
 #include "grid_common.hpp"
 
 using namespace vcpg;
@@ -36,6 +38,8 @@ constexpr int FT = 1024;           // threads per workgroup, fine pass
 constexpr uint32_t MAXB = 8192;    // buckets (LDS histogram of the coarse passes: 32 KB)
 // fine pass: a bucket of at most wcap records is staged in LDS in its final order (counters + staging <= 160 KB)
 constexpr uint32_t wcap(int) { return 4096u; }
+constexpr uint32_t QUEUE_FROM = 32;  // buckets of more windows than this hand them to k_part_fine_windows (at 6 windows per
+                                     // bucket -- 140 M uniform points -- the queue form was measured slower: 10.9 against 7.2 ms)
 
 // One record of the bucket-major intermediate: 16 bytes = the binary32 coordinates relative to the grid origin (what
 // the grid bins on and what the search kernels screen with, grid_common.hpp: rel32) + the point's index; in 2-D the
@@ -105,8 +109,9 @@ template <int GD, bool GROUPED>
 __global__ __launch_bounds__(PT) void k_part_hist(const double* __restrict__ c, int64_t n, int stride, GridP g,
                                                  const int32_t* __restrict__ group, int glo, int ghi, uint32_t csh,
                                                  uint32_t B, uint32_t chunk, uint32_t nchunk,
-                                                 uint32_t* __restrict__ counts) {
+                                                 uint32_t* __restrict__ counts, uint32_t* __restrict__ qcount) {
   extern __shared__ uint32_t h[];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *qcount = 0u;  // the fine pass's queue of windows (k_part_fine_windows)
   for (uint32_t k = threadIdx.x; k < B; k += PT) h[k] = 0;
   __syncthreads();
   const int64_t first = (int64_t)blockIdx.x * chunk;
@@ -204,7 +209,8 @@ __global__ __launch_bounds__(FT) void k_part_fine(const Rec* __restrict__ rec, u
                                                  const int32_t* __restrict__ group, uint32_t* __restrict__ cellstart,
                                                  float* __restrict__ sorted32, uint32_t* __restrict__ sord,
                                                  uint32_t* __restrict__ sidx_out, int32_t* __restrict__ sgroup,
-                                                 uint8_t* __restrict__ flags, uint32_t* __restrict__ pos) {
+                                                 uint8_t* __restrict__ flags, uint32_t* __restrict__ pos,
+                                                 uint2* __restrict__ queue, uint32_t* __restrict__ qcount) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   __shared__ uint32_t wsum[FT / 64];
   const uint32_t b = blockIdx.x;
@@ -266,11 +272,61 @@ __global__ __launch_bounds__(FT) void k_part_fine(const Rec* __restrict__ rec, u
     fine_flush<GD, GROUPED>(s, m, s32, sidx, ord, in_classed, group, sorted32, sord, sidx_out, sgroup, flags, pos);
     return;
   }
+  if (m > QUEUE_FROM * WCAP) {
+    // many windows: other workgroups assemble them (k_part_fine_windows), from the ranks left in rk and the bucket's
+    // slice of the cell table just stored -- this one would walk its m records once per window all by itself (a cloud
+    // that sits in ONE bucket: 445 k records, 109 windows, 37 ms)
+    __shared__ uint32_t q0;
+    const uint32_t nwin = (m + WCAP - 1) / WCAP;
+    if (threadIdx.x == 0) q0 = atomicAdd(qcount, nwin);
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < nwin; k += FT) queue[q0 + k] = make_uint2(b, k * WCAP);
+    return;
+  }
   for (uint32_t w0 = 0; w0 < m; w0 += WCAP) {
     for (uint32_t j = s + threadIdx.x; j < e; j += FT) {
       const Rec r = rec[j];
       uint32_t i;
       const uint32_t p = cnt[padded(rec_cell<GD>(r, g, i) - c0)] + rk[j] - s - w0;  // wraps below the window
+      if (p < WCAP) stage_put<GD>(s32, sidx, p, r, i);
+    }
+    __syncthreads();
+    fine_flush<GD, GROUPED>(s + w0, min(WCAP, m - w0), s32, sidx, ord, in_classed, group, sorted32, sord, sidx_out, sgroup,
+                            flags, pos);
+    __syncthreads();
+  }
+}
+
+// The windows of the large buckets, one per workgroup (queue filled by k_part_fine): final position of a record = its
+// cell's start (the cell table is in place) + its rank inside the cell (rk); the records whose position falls into the
+// window are staged in LDS and stored as full lines like everywhere else.
+template <int GD, bool GROUPED>
+__global__ __launch_bounds__(FT) void k_part_fine_windows(const Rec* __restrict__ rec, const uint32_t* __restrict__ rk,
+                                                         const uint32_t* __restrict__ base, const uint32_t* __restrict__ total,
+                                                         uint32_t nchunk, uint32_t B, GridP g,
+                                                         const uint32_t* __restrict__ ord, const uint8_t* __restrict__ in_classed,
+                                                         const int32_t* __restrict__ group,
+                                                         const uint32_t* __restrict__ cellstart, float* __restrict__ sorted32,
+                                                         uint32_t* __restrict__ sord, uint32_t* __restrict__ sidx_out,
+                                                         int32_t* __restrict__ sgroup, uint8_t* __restrict__ flags,
+                                                         uint32_t* __restrict__ pos, const uint2* __restrict__ queue,
+                                                         const uint32_t* __restrict__ qcount) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr uint32_t WCAP = wcap(GD);
+  constexpr uint32_t FPR = GD == 2 ? 2 : 4;
+  float* s32 = reinterpret_cast<float*>(lds);
+  uint32_t* sidx = reinterpret_cast<uint32_t*>(s32 + (size_t)WCAP * FPR);
+  const uint32_t nq = *qcount;
+  for (uint32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
+    const uint2 q = queue[qi];
+    const uint32_t b = q.x, w0 = q.y;
+    const uint32_t s = base[(size_t)b * nchunk];
+    const uint32_t e = (b + 1 < B) ? base[(size_t)(b + 1) * nchunk] : *total;
+    const uint32_t m = e - s;
+    for (uint32_t j = s + threadIdx.x; j < e; j += FT) {
+      const Rec r = rec[j];
+      uint32_t i;
+      const uint32_t p = cellstart[rec_cell<GD>(r, g, i)] + rk[j] - s - w0;  // wraps below the window
       if (p < WCAP) stage_put<GD>(s32, sidx, p, r, i);
     }
     __syncthreads();
@@ -408,9 +464,13 @@ int build(vcp_ctx* ctx, const GridBuildArgs& a) {
   const uint32_t CPB = 1u << pg.csh;
   const size_t lds_f = ((((size_t)CPB + CPB / 32) + 4) & ~3ull) * 4 + (size_t)wcap(GD) * ((GD == 2 ? 8 : 16) + 4);
   VCP_TRY(allow_lds(ctx, k_part_fine<GD, GROUPED>, lds_f));
+  // queue of (bucket, window) pairs for the buckets of many windows: at most n / WCAP + B entries, counter in front
+  VCP_TRY(vcp_ensure(ctx, ctx->b_fineq, ((size_t)a.n / wcap(GD) + pg.B + 8) * sizeof(uint2) + 64));
+  uint32_t* qcount = ctx->b_fineq.as<uint32_t>();
+  uint2* queue = reinterpret_cast<uint2*>(ctx->b_fineq.as<char>() + 64);
   vcp_phase(ctx, "part_hist");
   hipLaunchKernelGGL((k_part_hist<GD, GROUPED>), dim3(pg.nchunk), dim3(PT), lds_h, st, a.d_coords, a.n, a.stride, a.g,
-                     a.d_group, a.glo, a.ghi, pg.csh, pg.B, pg.chunk, pg.nchunk, counts);
+                     a.d_group, a.glo, a.ghi, pg.csh, pg.B, pg.chunk, pg.nchunk, counts, qcount);
   VCP_TRY(vcp_exclusive_scan_u32(ctx, counts, counts, (int64_t)nc, total));
   vcp_phase(ctx, "part_scatter");
   hipLaunchKernelGGL((k_part_scatter<GD, GROUPED>), dim3(pg.nchunk), dim3(PT), lds_h, st, a.d_coords, a.n, a.stride, a.g,
@@ -420,7 +480,15 @@ int build(vcp_ctx* ctx, const GridBuildArgs& a) {
   hipLaunchKernelGGL((k_part_fine<GD, GROUPED>), dim3(pg.B), dim3(FT), lds_f, st, rec, ctx->b_rank.as<uint32_t>(), counts,
                      total, pg.nchunk, pg.B,
                      pg.csh, a.g, a.d_ord, a.d_in_classed, a.d_group, a.cellstart, a.sorted32, a.sord, a.sidx, a.sgroup,
-                     a.flags, a.pos);
+                     a.flags, a.pos, queue, qcount);
+  {
+    const size_t lds_w = (size_t)wcap(GD) * ((GD == 2 ? 8 : 16) + 4);
+    VCP_TRY(allow_lds(ctx, k_part_fine_windows<GD, GROUPED>, lds_w));
+    const unsigned gw = (unsigned)std::min<size_t>(768, (size_t)a.n / wcap(GD) + 1);  // 3 workgroups per CU (48 KB LDS each in 2-D)
+    hipLaunchKernelGGL((k_part_fine_windows<GD, GROUPED>), dim3(gw), dim3(FT), lds_w, st, rec, ctx->b_rank.as<uint32_t>(),
+                       counts, total, pg.nchunk, pg.B, a.g, a.d_ord, a.d_in_classed, a.d_group, a.cellstart, a.sorted32,
+                       a.sord, a.sidx, a.sgroup, a.flags, a.pos, queue, qcount);
+  }
   VCP_HIP(ctx, hipGetLastError());
   return VCP_OK;
 }

@@ -651,17 +651,21 @@ __device__ __forceinline__ bool tile_bounds(CoreTile<GD>& t, bool live, const in
     for (int r = 0; r < NR; r++) rs[r] = re[r] = 0u;
   }
   __syncthreads();
+  // The lanes of a workgroup hold consecutive positions, i.e. non-decreasing cell ids, and both ends of a row range are
+  // non-decreasing in the cell id (cell id = cy * D0 + cx; the row starts at (cy + dy) * D0 + max(cx - 1, 0)): the union
+  // over a wave runs from the FIRST non-empty lane's start to the LAST non-empty lane's end -- two lane reads instead of
+  // two six-step shuffle reductions per row.
 #pragma unroll
   for (int r = 0; r < NR; r++) {
-    uint32_t a = rs[r] < re[r] ? rs[r] : NONE, b = rs[r] < re[r] ? re[r] : 0u;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-      a = min(a, (uint32_t)__shfl_xor((int)a, d, 64));
-      b = max(b, (uint32_t)__shfl_xor((int)b, d, 64));
-    }
-    if ((threadIdx.x & 63) == 0) {
-      atomicMin(&t.lo[r], a);
-      atomicMax(&t.hi[r], b);
+    const unsigned long long m = __ballot(rs[r] < re[r]);
+    if (m) {
+      const int f = __ffsll((long long)m) - 1, l = 63 - __clzll((long long)m);
+      const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)rs[r], f);
+      const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)re[r], l);
+      if ((threadIdx.x & 63) == 0) {
+        atomicMin(&t.lo[r], a);
+        atomicMax(&t.hi[r], b);
+      }
     }
   }
   __syncthreads();

@@ -32,7 +32,8 @@ using namespace vcpg;
 
 namespace {
 
-constexpr int PT = 512;            // threads per workgroup, histogram / scatter passes
+constexpr int PT = 1024;           // threads per workgroup, histogram / scatter passes (one workgroup per CU at 256 chunks:
+                                   // 512 threads measured 0.061 / 0.179 ms for the two passes, 1024 threads 0.043 / 0.153-0.175)
 constexpr int PCH_MIN = 8192;      // smallest chunk
 constexpr int FT = 1024;           // threads per workgroup, fine pass
 constexpr uint32_t MAXB = 8192;    // buckets (LDS histogram of the coarse passes: 32 KB)

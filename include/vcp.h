@@ -74,6 +74,13 @@ int vcp_release_workspace(vcp_ctx* ctx);
  * *total.  Device pointers; returns when the result is in place. */
 int vcp_selftest_scan_dev(vcp_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, int64_t n, int op, uint32_t* total);
 
+/* Self-test of the Horn step of vcp_icp (BC/ICP.cs:53-124, intended arithmetic), run on the HOST from the same source
+ * the device executes per round: sums[16] as vcp_icp_sums returns them, nd data points.  use_v != 0: V [16] is the
+ * eigenvector basis of a previous round (warm start; a basis that is not orthonormal to 1e-9 -- NaN included -- is
+ * replaced by the identity) and receives the basis found.  Returns 1 (solved), 0 (degenerate) or VCP_ERR_ARG.
+ * Needs no device and no context. */
+int vcp_selftest_horn(const double sums[16], int64_t nd, double V[16], int use_v, double R1[9], double T1[3]);
+
 /* -- per-phase device timing (hipEvents on the launch stream) ----------------------------- */
 /* When enabled, every compute call records hipEvents around each kernel phase on the stream
  * it launches on.  vcp_timing_get returns the phases of the LAST call. */

@@ -1,5 +1,6 @@
-"""Test tooling (not collected by pytest; lives under tests/ because it drives the oracle).  Randomised parity sweep on
-the GPU box: libvcp (through the C-ABI) against the order-free CPU oracle on clouds no
+"""Randomised parity sweep on the GPU box (drives the oracle, hence under tests/): as a script an open-ended sweep, and
+through run() the bounded, fixed-seed form that tests/test_fuzz_gpu.py runs under `pytest -m gpu` (one pass, per-case
+GPU time bound).  libvcp (through the C-ABI) against the order-free CPU oracle on clouds no
 fixed test has -- sizes from one point to a few million, uniform / clustered / lattice / duplicate-heavy / collinear
 shapes, far outliers, non-finite coordinates, every metric, isClassed inputs, cf presets -- plus the block pipeline.
 usage: python tests/fuzz_parity.py [seconds] [seed]"""
@@ -13,15 +14,28 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import binding as O  # noqa: E402  (test tooling: the oracle is the checker)
 from vtkcloudpoint_amd import _native as N  # noqa: E402
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
-rng = np.random.default_rng(seed)
-ctx = N.Context(0)
-t0 = time.time()
+rng = None   # set by run()
+ctx = None
 done = {"dbscan": 0, "blocks": 0}
+QUIET = [False]
+
+
+class Mismatch(AssertionError):
+    pass
+
+
+def fail(msg):
+    print(msg, flush=True)
+    raise Mismatch(msg)
+
+
+def say(*a, **k):
+    if not QUIET[0]:
+        print(*a, **k)
 
 
 KIND = [0]
+NN_LOG = [4.6]   # log10 of the largest model / data set of a nearest-neighbour case
 
 
 def cloud(n, dim):
@@ -60,8 +74,8 @@ def cloud(n, dim):
 def nn_case():
     """nearest neighbour of ICP (squared distances, lowest index on ties) and of the matching (sqrt distances) through
     every form: scalar cache (<= 512 model points), grid, and the full scan of non-finite models"""
-    nm = int(10 ** rng.uniform(0, 4.6))
-    nd = int(min(10 ** rng.uniform(0, 4.6), 2e8 / max(nm, 1)))
+    nm = int(10 ** rng.uniform(0, NN_LOG[0]))
+    nd = int(min(10 ** rng.uniform(0, NN_LOG[0]), 2e8 / max(nm, 1)))
     nd = max(nd, 1)
     kind = int(rng.integers(0, 5))
     if kind == 0:
@@ -87,8 +101,7 @@ def nn_case():
     want = O.find_closest(model, data)
     if not np.array_equal(nn, want):
         np.savez("gpurun_out/fuzz_fail_nn.npz", model=model, data=data)
-        print("MISMATCH nn nm=%d nd=%d kind=%d" % (nm, nd, kind), flush=True)
-        sys.exit(1)
+        fail("MISMATCH nn nm=%d nd=%d kind=%d" % (nm, nd, kind))
     if np.isfinite(model).all():
         M = np.eye(4)
         M[:3, 3] = rng.normal(0, 0.1, 3)
@@ -98,8 +111,7 @@ def nn_case():
         if not (np.array_equal(gm["nearest"], om["nearest"]) and np.array_equal(gm["is_matched"], om["is_matched"])
                 and np.array_equal(gm["matched_xyz"], om["matched_xyz"]) and gm["count"] == om["count"]):
             np.savez("gpurun_out/fuzz_fail_match.npz", model=model, data=data, M=M, md=md)
-            print("MISMATCH match K=%d T=%d kind=%d" % (min(nd, 20000), nm, kind), flush=True)
-            sys.exit(1)
+            fail("MISMATCH match K=%d T=%d kind=%d" % (min(nd, 20000), nm, kind))
     done["nn"] = done.get("nn", 0) + 1
 
 
@@ -146,95 +158,121 @@ def tools_case():
             ok = ok and np.array_equal(gb["labels"], ob["labels"]) and np.array_equal(gb["order"], ob["order"]) \
                 and gb["cluster_amount"] == ob["cluster_amount"] and gb["evals"] == ob["evals"]
     if not ok:
-        print("MISMATCH tools n=%d K=%d" % (n, K), flush=True)
-        sys.exit(1)
+        fail("MISMATCH tools n=%d K=%d" % (n, K))
     done["tools"] = done.get("tools", 0) + 1
 
 
-while time.time() - t0 < budget:
-    u = rng.random()
-    if u < 0.2:
-        nn_case()
-        continue
-    if u < 0.3:
-        tools_case()
-        continue
-    n = int(10 ** rng.uniform(0, 6.3))
-    metric = int(rng.integers(0, 3))
-    dim = 3 if metric == 2 else int(rng.integers(2, 4))
-    c = cloud(n, dim)
-    if KIND[0] == 5 and n > 50000:  # the CPU oracle grids the full bounding box: with far outliers its cells hold the whole
-        c = np.ascontiguousarray(c[:50000])  # bulk and it turns quadratic -- small clouds only for this shape
-        n = len(c)
-    fin = c[np.isfinite(c).all(axis=1)]
-    gd = 3 if metric == 2 else 2
-    # robust extent per axis (outliers and degenerate axes must not fool the density estimate: the CPU oracle is
-    # quadratic in the neighbourhood size); eps so that a typical point has from none to a few dozen neighbours
-    if len(fin) > 10:
-        q = np.percentile(fin[:, :gd], [2, 98], axis=0)
-        spans = np.maximum(q[1] - q[0], 0.0)
-    else:
-        spans = np.ones(gd)
-    live = spans[spans > 0]
-    vol = float(np.prod(live)) if len(live) else 1.0
-    deff = max(len(live), 1)
-    eps = float((rng.uniform(0.2, 30) * vol / max(n, 1)) ** (1.0 / deff))
-    if rng.random() < 0.15 and n <= 20000:  # round thresholds (exact ties on the lattices); small clouds only: on a
-        eps = float(rng.choice([0.0, 0.25, 1.0, 3.0]))  # cloud that fits inside eps the CPU oracle is quadratic
-    if eps == 0.0 and n > 30000:  # the CPU oracle's grid degenerates at eps = 0 (quadratic): small clouds only
-        c = np.ascontiguousarray(c[:30000])
-        n = len(c)
-    mp = int(rng.choice([1, 2, 3, 5, 7, 10, 16, 17, 40]))
-    cf = int(rng.integers(0, 5))
-    if rng.random() < 0.25:
-        cls = (rng.random(n) < 0.1).astype(np.uint8)
-        lab0 = (rng.integers(1, 4, n) * cls).astype(np.int32)
-    else:
-        cls, lab0 = None, None
-    print("case n=%d dim=%d metric=%d eps=%.6g mp=%d cf=%d cls=%d kind=%d" % (n, dim, metric, eps, mp, cf, cls is not None, KIND[0]),
-          end="", flush=True)
-    t1 = time.time()
-    g = ctx.dbscan(c, eps, mp, metric, cf, cls, lab0)
-    t2 = time.time()
-    print(" gpu %.3fs" % (t2 - t1), end="", flush=True)
-    o = O.dbscan(c, eps, mp, metric, cf, cls, lab0)
-    print(" cpu %.2fs" % (time.time() - t2), flush=True)
-    ok = (np.array_equal(g["labels"], o["labels"]) and np.array_equal(g["is_classed"], o["classed"])
-          and np.array_equal(g["is_core"], o["is_key"]) and g["cf"] == o["cf"] and g["evals"] == o["evals"])
-    if not ok:
-        np.savez("gpurun_out/fuzz_fail_dbscan.npz", c=c, eps=eps, mp=mp, metric=metric, cf=cf,
-                 cls=np.zeros(0) if cls is None else cls, lab0=np.zeros(0) if lab0 is None else lab0)
-        print("MISMATCH dbscan n=%d dim=%d metric=%d eps=%r mp=%d cf=%d cls=%s" % (n, dim, metric, eps, mp, cf, cls is not None),
-              flush=True)
-        sys.exit(1)
-    done["dbscan"] += 1
-    if rng.random() < 0.3 and n >= 2 and np.isfinite(c).all():
-        m2 = np.ascontiguousarray(c[:, :2])
-        pic = int(rng.choice([1, 3, 20, 200, 5000]))
-        try:
-            ob = O.block_pipeline(m2, eps, mp, pic, 3)
-        except O.OracleError as e:
+def run(budget=300.0, seed=12345, max_log_n=6.3, gpu_bound=None, device=0, quiet=False, nn_log=4.6):
+    """One sweep of `budget` seconds from `seed`.  max_log_n: log10 of the largest DBSCAN cloud; gpu_bound: optional
+    function n -> seconds, the GPU time a DBSCAN call on n points may take (the sweep found two cliffs that way: eps = 0
+    with far outliers, a cloud inside one eps-ball).  Raises Mismatch on the first disagreement."""
+    global rng, ctx
+    rng = np.random.default_rng(seed)
+    own = ctx is None
+    if own:
+        ctx = N.Context(device)
+    QUIET[0] = quiet
+    NN_LOG[0] = nn_log
+    for k in list(done):
+        done[k] = 0
+    os.makedirs("gpurun_out", exist_ok=True)
+    t0 = time.time()
+    while time.time() - t0 < budget:
+        u = rng.random()
+        if u < 0.2:
+            nn_case()
+            continue
+        if u < 0.3:
+            tools_case()
+            continue
+        n = int(10 ** rng.uniform(0, max_log_n))
+        metric = int(rng.integers(0, 3))
+        dim = 3 if metric == 2 else int(rng.integers(2, 4))
+        c = cloud(n, dim)
+        if KIND[0] == 5 and n > 50000:  # the CPU oracle grids the full bounding box: with far outliers its cells hold the whole
+            c = np.ascontiguousarray(c[:50000])  # bulk and it turns quadratic -- small clouds only for this shape
+            n = len(c)
+        fin = c[np.isfinite(c).all(axis=1)]
+        gd = 3 if metric == 2 else 2
+        # robust extent per axis (outliers and degenerate axes must not fool the density estimate: the CPU oracle is
+        # quadratic in the neighbourhood size); eps so that a typical point has from none to a few dozen neighbours
+        if len(fin) > 10:
+            q = np.percentile(fin[:, :gd], [2, 98], axis=0)
+            spans = np.maximum(q[1] - q[0], 0.0)
+        else:
+            spans = np.ones(gd)
+        live = spans[spans > 0]
+        vol = float(np.prod(live)) if len(live) else 1.0
+        deff = max(len(live), 1)
+        eps = float((rng.uniform(0.2, 30) * vol / max(n, 1)) ** (1.0 / deff))
+        if rng.random() < 0.15 and n <= 20000:  # round thresholds (exact ties on the lattices); small clouds only: on a
+            eps = float(rng.choice([0.0, 0.25, 1.0, 3.0]))  # cloud that fits inside eps the CPU oracle is quadratic
+        if eps == 0.0 and n > 30000:  # the CPU oracle's grid degenerates at eps = 0 (quadratic): small clouds only
+            c = np.ascontiguousarray(c[:30000])
+            n = len(c)
+        mp = int(rng.choice([1, 2, 3, 5, 7, 10, 16, 17, 40]))
+        cf = int(rng.integers(0, 5))
+        if rng.random() < 0.25:
+            cls = (rng.random(n) < 0.1).astype(np.uint8)
+            lab0 = (rng.integers(1, 4, n) * cls).astype(np.int32)
+        else:
+            cls, lab0 = None, None
+        say("case n=%d dim=%d metric=%d eps=%.6g mp=%d cf=%d cls=%d kind=%d" % (n, dim, metric, eps, mp, cf, cls is not None, KIND[0]),
+            end="", flush=True)
+        t1 = time.time()
+        g = ctx.dbscan(c, eps, mp, metric, cf, cls, lab0)
+        t2 = time.time()
+        say(" gpu %.3fs" % (t2 - t1), end="", flush=True)
+        if gpu_bound is not None and done["dbscan"] > 0 and t2 - t1 > gpu_bound(n):  # (the first call allocates)
+            fail("SLOW dbscan n=%d dim=%d metric=%d eps=%r mp=%d kind=%d: %.3f s on the GPU" % (n, dim, metric, eps, mp, KIND[0], t2 - t1))
+        o = O.dbscan(c, eps, mp, metric, cf, cls, lab0)
+        say(" cpu %.2fs" % (time.time() - t2), flush=True)
+        ok = (np.array_equal(g["labels"], o["labels"]) and np.array_equal(g["is_classed"], o["classed"])
+              and np.array_equal(g["is_core"], o["is_key"]) and g["cf"] == o["cf"] and g["evals"] == o["evals"])
+        if not ok:
+            np.savez("gpurun_out/fuzz_fail_dbscan.npz", c=c, eps=eps, mp=mp, metric=metric, cf=cf,
+                     cls=np.zeros(0) if cls is None else cls, lab0=np.zeros(0) if lab0 is None else lab0)
+            fail("MISMATCH dbscan n=%d dim=%d metric=%d eps=%r mp=%d cf=%d cls=%s" % (n, dim, metric, eps, mp, cf, cls is not None))
+        done["dbscan"] += 1
+        if rng.random() < 0.3 and n >= 2 and np.isfinite(c).all():
+            m2 = np.ascontiguousarray(c[:, :2])
+            pic = int(rng.choice([1, 3, 20, 200, 5000]))
             try:
-                ctx.dbscan_blocks(m2, eps, mp, pic, 3)
-                print("MISSING ERROR blocks n=%d oracle code %d" % (n, e.code), flush=True)
-                sys.exit(1)
-            except N.VcpError:
-                continue
-        try:
-            gb = ctx.dbscan_blocks(m2, eps, mp, pic, 3)
-        except N.VcpError as e:
-            if e.code == -5:  # more than 2^26 blocks: the library's documented limit (the C# would need a 4 GB array)
-                continue
-            raise
-        okb = (np.array_equal(gb["labels"], ob["labels"]) and np.array_equal(gb["order"], ob["order"])
-               and np.array_equal(gb["block_of"], ob["block_of"]) and gb["kept"] == ob["kept"]
-               and gb["cluster_amount"] == ob["cluster_amount"] and gb["evals"] == ob["evals"])
-        if not okb:
-            np.savez("gpurun_out/fuzz_fail_blocks.npz", m=m2, eps=eps, mp=mp, pic=pic)
-            print("MISMATCH blocks n=%d eps=%r mp=%d pic=%d" % (n, eps, mp, pic), flush=True)
-            sys.exit(1)
-        done["blocks"] += 1
-    if (done["dbscan"] % 50) == 0:
-        print("%.0f s: %d dbscan, %d block pipelines agree" % (time.time() - t0, done["dbscan"], done["blocks"]), flush=True)
-print("OK: %d dbscan calls, %d block pipelines, %d nearest-neighbour / matching cases bit-exact and %d centroid / merge / keyed-"
-      "pipeline cases against the oracle (seed %d)" % (done["dbscan"], done["blocks"], done.get("nn", 0), done.get("tools", 0), seed))
+                ob = O.block_pipeline(m2, eps, mp, pic, 3)
+            except O.OracleError as e:
+                try:
+                    ctx.dbscan_blocks(m2, eps, mp, pic, 3)
+                    fail("MISSING ERROR blocks n=%d oracle code %d" % (n, e.code))
+                except N.VcpError:
+                    continue
+            try:
+                gb = ctx.dbscan_blocks(m2, eps, mp, pic, 3)
+            except N.VcpError as e:
+                if e.code == -5:  # more than 2^26 blocks: the library's documented limit (the C# would need a 4 GB array)
+                    continue
+                raise
+            okb = (np.array_equal(gb["labels"], ob["labels"]) and np.array_equal(gb["order"], ob["order"])
+                   and np.array_equal(gb["block_of"], ob["block_of"]) and gb["kept"] == ob["kept"]
+                   and gb["cluster_amount"] == ob["cluster_amount"] and gb["evals"] == ob["evals"])
+            if not okb:
+                np.savez("gpurun_out/fuzz_fail_blocks.npz", m=m2, eps=eps, mp=mp, pic=pic)
+                fail("MISMATCH blocks n=%d eps=%r mp=%d pic=%d" % (n, eps, mp, pic))
+            done["blocks"] += 1
+        if (done["dbscan"] % 50) == 0:
+            say("%.0f s: %d dbscan, %d block pipelines agree" % (time.time() - t0, done["dbscan"], done["blocks"]), flush=True)
+    msg = ("OK: %d dbscan calls, %d block pipelines, %d nearest-neighbour / matching cases bit-exact and %d centroid / merge / "
+           "keyed-pipeline cases against the oracle (seed %d)" % (done["dbscan"], done["blocks"], done.get("nn", 0),
+                                                               done.get("tools", 0), seed))
+    print(msg, flush=True)
+    if own:
+        ctx.close()
+        ctx = None
+    return dict(done)
+
+
+if __name__ == "__main__":
+    try:
+        run(float(sys.argv[1]) if len(sys.argv) > 1 else 300.0, int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+    except Mismatch:
+        sys.exit(1)
+

@@ -50,3 +50,37 @@ def test_product_does_not_import_the_oracle():
                 assert "vcp_oracle" not in text and "libvcp_oracle" not in text, fn
     with open(os.path.join(ROOT, "vtkcloudpoint_amd", "csrc", "Makefile")) as f:
         assert "oracle" not in f.read()
+
+
+def test_horn_step_cold_start_on_a_nan_or_garbage_basis():
+    """The Horn step of vcp_icp (host run of the same __host__ __device__ source, no device needed): a warm-start basis
+    full of NaN, or one that is not orthonormal, must take the cold-start path -- fmax() would have dropped the NaN."""
+    import numpy as np
+    from vtkcloudpoint_amd import _native
+    lib = _native.lib()
+    rng = np.random.default_rng(5)
+    P = rng.uniform(-3, 3, (500, 3))
+    a = 0.4
+    Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+    Y = P @ Rz.T + np.array([0.5, -1.0, 2.0])
+    sums = np.concatenate([P.sum(0), Y.sum(0), (P[:, :, None] * Y[:, None, :]).sum(0).reshape(9), [0.0]])
+
+    def solve(V, use):
+        R, T = np.zeros(9), np.zeros(3)
+        Vb = None if V is None else np.ascontiguousarray(V, np.float64).reshape(16).copy()
+        rc = lib.vcp_selftest_horn(sums.ctypes.data_as(C.c_void_p), C.c_int64(len(P)),
+                                   None if Vb is None else Vb.ctypes.data_as(C.c_void_p), C.c_int(use),
+                                   R.ctypes.data_as(C.c_void_p), T.ctypes.data_as(C.c_void_p))
+        assert rc == 1
+        return R.reshape(3, 3), T, Vb
+
+    R0, T0, _ = solve(None, 0)
+    assert np.allclose(R0, Rz, atol=1e-12) and np.allclose(T0, [0.5, -1.0, 2.0], atol=1e-12)
+    Rc, Tc, Vc = solve(np.eye(4), 1)             # identity basis = the cold start, bit for bit
+    assert np.array_equal(Rc, R0) and np.array_equal(Tc, T0)
+    for bad in (np.full((4, 4), np.nan), rng.uniform(-1, 1, (4, 4)), np.eye(4) * 2.0):
+        Rb, Tb, Vb = solve(bad, 1)
+        assert np.array_equal(Rb, R0) and np.array_equal(Tb, T0)
+        assert np.array_equal(Vb, Vc)             # the basis stored back is the cold start's
+    Rw, Tw, _ = solve(Vc.reshape(4, 4), 1)        # a good basis: warm start, same answer to rounding
+    assert np.allclose(Rw, R0, atol=1e-12) and np.allclose(Tw, T0, atol=1e-12)

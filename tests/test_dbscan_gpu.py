@@ -232,6 +232,23 @@ def test_lattice_every_neighbour_exactly_on_eps(vcp_ctx, oracle, metric, dim):
             assert np.array_equal(g["is_core"], o["is_key"])
 
 
+@pytest.mark.parametrize("metric", [N.L1_2D, N.L2_2D, N.L2_3D])
+@pytest.mark.parametrize("scale", [1e-20, 1e-25, 1e19, 1e30, 1e150])
+def test_lattice_at_scales_where_binary32_under_or_overflows(vcp_ctx, oracle, metric, scale):
+    """The binary32 screen's error model is relative rounding: where the binary32 copies, their differences or their
+    squares leave binary32's normal range (coordinates x 1e-20: squares are subnormal; x 1e19 and beyond: squares or the
+    copies themselves overflow) screen_bounds hands every candidate to the exact binary64 test.  Lattice with eps on the
+    lattice step, so that every neighbour pair sits exactly on the threshold."""
+    rng = np.random.default_rng(77 + metric)
+    nd = 3 if metric == N.L2_3D else 2
+    c = rng.integers(0, 40, size=(8_000, nd)).astype(np.float64) * scale
+    for mp in (3, 8):
+        o = oracle.dbscan(c, scale, mp, metric)
+        g = vcp_ctx.dbscan(c, scale, mp, metric)
+        _same(g, o, "scale %g mp %d" % (scale, mp))
+        assert np.array_equal(g["is_core"], o["is_key"])
+
+
 def test_eps_zero_with_far_outliers_is_duplicate_grouping_and_fast(vcp_ctx, oracle):
     """eps = 0: a point's neighbours are its exact duplicates, so clusters are the duplicate groups of >= minPts points,
     numbered by first occurrence.  With a few far outliers the grid used to be cut over the untrimmed range (the trimming

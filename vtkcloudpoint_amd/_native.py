@@ -27,6 +27,7 @@ SYMBOLS = [
     "vcp_match", "vcp_mcc", "vcp_assign_truths", "vcp_icp_vtklike", "vcp_import_convert",
     "vcp_slab_begin", "vcp_slab_comps", "vcp_slab_finish", "vcp_release_workspace", "vcp_selftest_scan_dev",
     "vcp_centroids_weighted", "vcp_dbscan_blocks_keyed", "vcp_blocks_begin_keyed", "vcp_blocks_begin_keyed_dev",
+    "vcp_selftest_horn",
 ]
 
 

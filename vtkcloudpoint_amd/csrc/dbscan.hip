@@ -1601,6 +1601,11 @@ Screen screen_bounds(int metric, int gd, double thr, double E) {
   sc.lo = -1.0f;
   sc.hi = INFINITY;
   if (!(thr >= 0.0) || !std::isfinite(E)) return sc;  // NaN / negative thresholds and unbounded clouds: all exact
+  // The error model below is RELATIVE rounding (u = 2^-24).  It does not hold where binary32 underflows (conversions
+  // and squares of magnitude below 2^-126 carry an absolute error of 2^-150) or overflows (a copy or a square beyond
+  // FLT_MAX is inf): thresholds that small (thr = 0 is fine: identical points have identical copies, value 0) and
+  // clouds that large take the exact path for every candidate.
+  if ((thr > 0.0 && thr < 1e-30) || E > 1e18) return sc;
   const double u = 5.9604644775390625e-08;
   const double alpha = 2.0 * u * E * (1.0 + 2.0 * u);
   double err;
@@ -1799,7 +1804,18 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
     cellw *= 1.25;
   }
   if (ncells > budget) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "grid does not fit the cell budget");
-  g.inv_h = std::isinf(cellw) ? 0.0 : 1.0 / cellw;
+  // largest |coordinate - grid origin| over the finite input: the true bounding box, not the (possibly trimmed) grid
+  double Emax = 0.0;
+  for (int a = 0; a < GD; a++) Emax = std::fmax(Emax, std::fmax(std::fabs(bbox[a] - g.mn[a]), std::fabs(bbox[3 + a] - g.mn[a])));
+  if (!std::isfinite(Emax))
+    return vcp_fail(ctx, VCP_ERR_UNSUPPORTED, "the cloud's extent overflows binary64 (coordinate - origin is infinite)");
+  // binary32 keeps the relative precision the cell edge and the screen bounds count on only inside its normal range:
+  // a cloud whose extent is far outside it (coordinates x 1e150: the copies would be inf, every point in an edge cell;
+  // x 1e-40: subnormal copies) is binned and screened on (coordinate - origin) * 2^k with the extent brought to [1, 2).
+  // A power of two is exact, so everything above holds for the scaled values; clouds of ordinary size keep k = 0.
+  g.scale = 1.0;
+  if (Emax > 1e30 || (Emax > 0.0 && Emax < 1e-20)) g.scale = std::ldexp(1.0, -std::ilogb(Emax));
+  g.inv_h = std::isinf(cellw) ? 0.0 : 1.0 / (cellw * g.scale);
   g.ncells = (uint32_t)ncells;
 
   // 3. workspace
@@ -1828,11 +1844,9 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   uint32_t* pos = ctx->b_pos.as<uint32_t>();
   double* sorted = ctx->b_sorted.as<double>();
   float* sorted32 = ctx->b_sorted32.as<float>();
-  // largest |coordinate - grid origin| over the finite input: the true bounding box, not the (possibly trimmed) grid
-  double Emax = 0.0;
-  for (int a = 0; a < GD; a++) Emax = std::fmax(Emax, std::fmax(std::fabs(bbox[a] - g.mn[a]), std::fabs(bbox[3 + a] - g.mn[a])));
   static const bool screen_off = getenv("VCP_NO_SCREEN") != nullptr;
-  Screen sc = screen_bounds(METRIC, GD, thr, Emax);
+  // the screen compares values of the SCALED copies: threshold and extent in the same units
+  Screen sc = screen_bounds(METRIC, GD, METRIC == VCP_L1_2D ? thr * g.scale : thr * g.scale * g.scale, Emax * g.scale);
   if (screen_off) sc = Screen{-1.0f, INFINITY};
   uint32_t* sord = ctx->b_sidx.as<uint32_t>();
   uint8_t* flags = ctx->b_flags.as<uint8_t>();

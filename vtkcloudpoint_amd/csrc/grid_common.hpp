@@ -11,7 +11,9 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 struct GridP {
   double mn[3];
-  double inv_h;
+  double inv_h;     // cells per unit of the SCALED relative coordinate
+  double scale;     // power of two applied to (coordinate - origin) before it is rounded to binary32: 1 unless the cloud's
+                    // extent is outside the range where binary32 keeps its relative precision (run_dbscan)
   int D[3];         // cells per axis
   uint32_t ncells;
 };
@@ -31,7 +33,8 @@ __device__ __forceinline__ uint32_t cell_id(const GridP& g, int cx, int cy, int 
 // partition build can carry binary32 records.  rel32 is monotone in x, hence so is the cell index; the cell width
 // includes the rounding of two such values (run(): cellw), so two points within eps of each other on an axis still
 // land in the same or in adjacent cells.
-__device__ __forceinline__ float rel32(double x, double mn) { return (float)(x - mn); }
+// (the factor is a power of two: exact, so the scaled value rounds exactly like the unscaled one would in a wider format)
+__device__ __forceinline__ float rel32(double x, double mn, double scale) { return (float)((x - mn) * scale); }
 
 __device__ __forceinline__ int cell_coord32(float f, double inv_h, int D) {
   double u = (double)f * inv_h;
@@ -40,8 +43,8 @@ __device__ __forceinline__ int cell_coord32(float f, double inv_h, int D) {
   return 0;  // below the minimum or NaN
 }
 
-__device__ __forceinline__ int cell_coord(double x, double mn, double inv_h, int D) {
-  return cell_coord32(rel32(x, mn), inv_h, D);
+__device__ __forceinline__ int cell_coord(double x, double mn, double scale, double inv_h, int D) {
+  return cell_coord32(rel32(x, mn, scale), inv_h, D);
 }
 
 template <int GD>
@@ -83,10 +86,10 @@ __device__ __forceinline__ void load_in(const double* __restrict__ c, int64_t i,
 
 template <int GD>
 __device__ __forceinline__ uint32_t cell_of(const double* q, const GridP& g, int* cc) {
-  cc[0] = cell_coord(q[0], g.mn[0], g.inv_h, g.D[0]);
-  cc[1] = cell_coord(q[1], g.mn[1], g.inv_h, g.D[1]);
+  cc[0] = cell_coord(q[0], g.mn[0], g.scale, g.inv_h, g.D[0]);
+  cc[1] = cell_coord(q[1], g.mn[1], g.scale, g.inv_h, g.D[1]);
   cc[2] = 0;
-  if (GD == 3) cc[2] = cell_coord(q[2], g.mn[2], g.inv_h, g.D[2]);
+  if (GD == 3) cc[2] = cell_coord(q[2], g.mn[2], g.scale, g.inv_h, g.D[2]);
   return cell_id<GD>(g, cc[0], cc[1], cc[2]);
 }
 
@@ -125,10 +128,10 @@ __device__ __forceinline__ void load_pt32(const float* __restrict__ c, int64_t i
 template <int GD>
 __device__ __forceinline__ void store_pt32(float* __restrict__ c, int64_t i, const double* q, const GridP& g) {
   if (GD == 2) {
-    *reinterpret_cast<float2*>(c + 2 * i) = make_float2(rel32(q[0], g.mn[0]), rel32(q[1], g.mn[1]));
+    *reinterpret_cast<float2*>(c + 2 * i) = make_float2(rel32(q[0], g.mn[0], g.scale), rel32(q[1], g.mn[1], g.scale));
   } else {
     *reinterpret_cast<float4*>(c + 4 * i) =
-        make_float4(rel32(q[0], g.mn[0]), rel32(q[1], g.mn[1]), rel32(q[2], g.mn[2]), 0.0f);
+        make_float4(rel32(q[0], g.mn[0], g.scale), rel32(q[1], g.mn[1], g.scale), rel32(q[2], g.mn[2], g.scale), 0.0f);
   }
 }
 

@@ -25,6 +25,8 @@
 // is order-free by construction (numbering by smallest LIST position, border rule by max id), which
 // tests/test_determinism_gpu.py re-checks on the GPU.
 #include <algorithm>
+#include <mutex>
+#include <unordered_map>
 
 #include "grid_common.hpp"
 
@@ -75,7 +77,7 @@ __device__ __forceinline__ uint32_t point_cell(const double* __restrict__ c, int
   int cc[3];
   load_in<GD>(c, i, stride, q);
 #pragma unroll
-  for (int a = 0; a < GD; a++) qf[a] = rel32(q[a], g.mn[a]);
+  for (int a = 0; a < GD; a++) qf[a] = rel32(q[a], g.mn[a], g.scale);
   return cell_of32<GD>(qf, g, cc);
 }
 
@@ -439,16 +441,23 @@ __global__ __launch_bounds__(OWT) void k_out_write(const uint2* __restrict__ rec
   }
 }
 
-// dynamic LDS beyond 64 KB has to be allowed per kernel (once per process and size)
-template <class K>
-int allow_lds(vcp_ctx* ctx, K kernel, size_t bytes) {
-  static size_t allowed = 64 * 1024;
-  if (bytes > allowed) {
-    VCP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)bytes));
-    allowed = bytes;
+// dynamic LDS beyond 64 KB has to be allowed per kernel: the record is keyed on the kernel's ADDRESS (instantiations
+// with the same signature are different kernels), one entry per kernel and process
+int allow_lds(vcp_ctx* ctx, const void* kernel, size_t bytes) {
+  static std::mutex mu;
+  static std::unordered_map<uint64_t, size_t> allowed;  // (kernel, device): code objects are loaded per device
+  std::lock_guard<std::mutex> lk(mu);
+  const uint64_t key = (uint64_t)reinterpret_cast<uintptr_t>(kernel) * 64u + (uint64_t)(ctx->device & 63);
+  size_t& have = allowed.emplace(key, (size_t)64 * 1024).first->second;
+  if (bytes > have) {
+    VCP_HIP(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    have = bytes;
   }
   return VCP_OK;
+}
+template <class K>
+int allow_lds(vcp_ctx* ctx, K kernel, size_t bytes) {
+  return allow_lds(ctx, reinterpret_cast<const void*>(kernel), bytes);
 }
 
 template <int GD, bool GROUPED>
@@ -524,11 +533,12 @@ static int output_partition(vcp_ctx* ctx, const GridOutputArgs& a) {
   VCP_TRY(vcp_ensure(ctx, ctx->b_rec, (size_t)OB << (OWSH + 3)));
   uint32_t* gcur = ctx->b_outcur.as<uint32_t>();
   uint2* rec = ctx->b_rec.as<uint2>();
+  // every fallible host step comes BEFORE the scatter: between the two kernels the window cursors are not zero
+  VCP_TRY(allow_lds(ctx, k_out_write<OWSH>, (size_t)4 << OWSH));
   vcp_phase(ctx, "out_scatter");
   hipLaunchKernelGGL(k_out_scatter<OWSH>, dim3(vcp_blocks(a.n, OT * OPT)), dim3(OT), (size_t)OB * 4, st, a.sord, a.labk, a.n,
                      OB, gcur, rec);
   vcp_phase(ctx, "out_write");
-  VCP_TRY(allow_lds(ctx, k_out_write<OWSH>, (size_t)4 << OWSH));
   hipLaunchKernelGGL(k_out_write<OWSH>, dim3(OB), dim3(OWT), (size_t)4 << OWSH, st, rec, a.n, a.have_in_classed, a.cf_in,
                      a.labels, a.is_core, a.is_classed, a.counters, gcur);
   VCP_HIP(ctx, hipGetLastError());

@@ -169,7 +169,10 @@ __global__ __launch_bounds__(TB) void k_icp_pass(const double* __restrict__ mode
     const double pc0 = p[0] - cen0, pc1 = p[1] - cen1, pc2 = p[2] - cen2;
     const float q0 = (float)pc0, q1 = (float)pc1, q2 = (float)pc2;
     const double S = fmax(mmax, fmax(fabs(pc0), fmax(fabs(pc1), fabs(pc2))));
-    const float tol2 = (float)(S * S * 7.62939453125e-06) * 1.0001f;  // 2^-17 S^2, rounded up (NaN -> all candidates)
+    // 2^-17 S^2, rounded up (NaN -> all candidates; also outside binary32's normal range, where the relative rounding
+    // model behind the bound does not hold)
+    const float tol2r = (float)(S * S * 7.62939453125e-06) * 1.0001f;
+    const float tol2 = ((float)(S * S) < 1.0e37f && tol2r >= 1.0e-30f) ? tol2r : NAN;
     // pass 1 (binary32): smallest and second smallest screened score, four model points per trip
     float b1 = INFINITY, b2 = INFINITY;
     int j1 = 0;
@@ -379,7 +382,9 @@ __global__ __launch_bounds__(TB) void k_icp_pass_small(const double* __restrict_
       const double S = fmax(mmax, fmax(fabs(pc0), fmax(fabs(pc1), fabs(pc2))));
       const float t2 = (float)(S * S * tolk) * 1.0001f;
       // scores are bounded by 4.5 S^2: beyond binary32 range (or NaN) the point goes to the exact scan
-      tol2[h] = (float)(S * S) < 1.0e37f ? t2 : NAN;
+      // outside binary32's normal range the rounding model behind tolk does not hold (underflow: absolute errors of
+      // 2^-149; overflow: inf scores): NaN = every candidate goes through the binary64 comparison
+      tol2[h] = ((float)(S * S) < 1.0e37f && t2 >= 1.0e-30f) ? t2 : NAN;
     }
     const f32x2 nq0 = {-q[0][0], -q[1][0]}, nq1 = {-q[0][1], -q[1][1]}, nq2 = {-q[0][2], -q[1][2]};
     float b1[2] = {INFINITY, INFINITY}, b2[2] = {INFINITY, INFINITY};
@@ -545,7 +550,7 @@ __host__ __device__ inline bool horn(const double s[16], long long nd, double R1
   }
   bool warm = Vst != nullptr;
   if (warm) {
-    double dev = 0.0;  // | V^T V - I |_max
+    bool ortho = true;  // | V^T V - I |_max <= 1e-9, tested per entry: fmax would drop a NaN
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -559,9 +564,9 @@ __host__ __device__ inline bool horn(const double s[16], long long nd, double R1
         double d = 0.0;
 #pragma unroll
         for (int k = 0; k < 4; k++) d += V[k][i] * V[k][j];
-        dev = fmax(dev, fabs(d - (i == j ? 1.0 : 0.0)));
+        ortho = ortho && (fabs(d - (i == j ? 1.0 : 0.0)) <= 1e-9);  // false for NaN
       }
-    warm = dev <= 1e-9;  // false for NaN too
+    warm = ortho;
   }
   if (warm) {
     double QV[4][4];
@@ -886,6 +891,12 @@ int vcp_icp_vtklike(vcp_ctx* ctx, const double* source, int64_t ns, const double
   if (mean_dist) *mean_dist = std::sqrt(fin.d / (double)nb);
   if (iters_o) *iters_o = fin.round;
   return VCP_OK;
+}
+
+// Host-side run of the Horn step the device executes per round (same source: horn() is __host__ __device__).
+int vcp_selftest_horn(const double sums[16], int64_t nd, double V[16], int use_v, double R1[9], double T1[3]) {
+  if (!sums || !R1 || !T1 || nd <= 0 || (use_v && !V)) return VCP_ERR_ARG;
+  return horn(sums, (long long)nd, R1, T1, use_v ? V : nullptr) ? 1 : 0;
 }
 
 int vcp_icp_sums(vcp_ctx* ctx, const double* model, int64_t nm, const double* data, int64_t nd, const double R[9],

@@ -105,19 +105,25 @@ def allgather_known(local_full, ranges, extra, group=None, force=False):
 
 
 def sharded_blocks(backend, motor, eps, min_pts, pts_in_cell, small_max=3, group=None, device="cuda",
-                   motor_dev_ptr=None, local=None, labels=None, force_collective=False):
+                   motor_dev_ptr=None, local=None, labels=None, force_collective=False, n=None):
     """Run the block pipeline with the per-block step sharded over the ranks of `group`.
 
     backend: object with blocks_begin / blocks_share / blocks_cluster_dev / blocks_finish_dev (a
     vtkcloudpoint_amd._native.Context; the CPU tests pass an oracle-backed stand-in with the same methods
     that works on CPU tensors).  local [>= m] / labels [>= n]: optional preallocated int32 work / output tensors
-    (a timed loop passes them so that no allocation or fill sits in the step).
+    (a timed loop passes them so that no allocation or fill sits in the step).  motor may be None when motor_dev_ptr
+    names a device-resident cloud; n is then required.
     Returns dict(labels [n] int32 tensor, local [m], kept, cluster_amount, ..., collective_bytes).
     """
     rank, world = _world(group)
-    n = len(motor) if motor is not None else None
+    if motor is not None:
+        if n is not None and int(n) != len(motor):
+            raise ValueError("n = %d disagrees with len(motor) = %d" % (int(n), len(motor)))
+        n = len(motor)
+    elif n is None:
+        raise ValueError("a device-only cloud (motor=None, motor_dev_ptr) needs its point count n")
+    n = int(n)
     if motor_dev_ptr is not None:
-        n = int(n if n is not None else 0)
         info = backend.blocks_begin(None, eps, min_pts, pts_in_cell, small_max, device_ptr=motor_dev_ptr, n=n)
     else:
         info = backend.blocks_begin(motor, eps, min_pts, pts_in_cell, small_max)

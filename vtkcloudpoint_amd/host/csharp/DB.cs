@@ -1,8 +1,11 @@
 // DB.cs -- drop-in replacement for vtkPointCloud/BaseClass/DB.cs (the v1.0 class; its only use is commented out at
 // FrmMain.cs:38): same public surface -- clusterAmount, pointsAmount, static iritatorNum, static getDisP / isKeyPoint /
 // expandCluster, dbscan(List<Point3D>, double, int).  dbscan marshals to flat arrays and calls vcp_dbscan with the
-// signed metric and the ifShown mask; the two statics keep the C#'s own control flow (they are public API of the class
-// and are not on any hot path).
+// signed metric and the ifShown mask.
+// RETAINED FROM THE ORIGINAL: the bodies of the three public statics below (getDisP, isKeyPoint, expandCluster) are the
+// reference's own lines (BaseClass/DB.cs:14-91) minus comments and minus the never-matching dedupe loop.  They are public
+// API of the class, any caller may invoke them directly, and they must behave identically; they are on no hot path and
+// have no native counterpart.  Everything else in this file is new.
 using System;
 using System.Collections;
 using System.Collections.Generic;
@@ -73,7 +76,8 @@ namespace vtkPointCloud
             }
             byte[] isCore = new byte[n], isClassed = new byte[n];
             int cfOut; long evals;
-            VcpNative.Check(VcpNative.vcp_dbscan(VcpNative.Ctx, xy, n, 2, VcpNative.VCP_SIGNED_SUM_2D, e, minPts, 0, shown,
+            using (VcpNative.Lease c = VcpNative.Rent())
+                VcpNative.Check(c, VcpNative.vcp_dbscan(c.Ctx, xy, n, 2, VcpNative.VCP_SIGNED_SUM_2D, e, minPts, 0, shown,
                 classed, labels, isCore, isClassed, out cfOut, out evals));
             for (int i = 0; i < n; i++)
             {

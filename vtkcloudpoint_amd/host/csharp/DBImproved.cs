@@ -40,7 +40,8 @@ namespace vtkPointCloud
             }
             byte[] isCore = new byte[n], isClassed = new byte[n];
             int cfOut; long evals;
-            VcpNative.Check(VcpNative.vcp_dbscan(VcpNative.Ctx, xy, n, 2, VcpNative.VCP_L1_2D, e, minPts, cf, null,
+            using (VcpNative.Lease c = VcpNative.Rent())
+                VcpNative.Check(c, VcpNative.vcp_dbscan(c.Ctx, xy, n, 2, VcpNative.VCP_L1_2D, e, minPts, cf, null,
                 any ? classed : null, labels, isCore, isClassed, out cfOut, out evals));
             for (int i = 0; i < n; i++)
             {

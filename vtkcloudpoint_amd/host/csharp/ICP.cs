@@ -22,7 +22,8 @@ namespace vtkPointCloud
             if (data.Count == 0) return;
             double[] r = new double[9], t = new double[3];
             double sse, rmse; int iters;
-            VcpNative.Check(VcpNative.vcp_icp(VcpNative.Ctx, Flatten(model), model.Count, Flatten(data), data.Count, e,
+            using (VcpNative.Lease c = VcpNative.Rent())
+                VcpNative.Check(c, VcpNative.vcp_icp(c.Ctx, Flatten(model), model.Count, Flatten(data), data.Count, e,
                 maxIter, VcpNative.VCP_STOP_SSE_DELTA, r, t, out sse, out rmse, out iters));
             if (iters == 1 && sse < e) return;
             for (int i = 0; i < 3; i++)

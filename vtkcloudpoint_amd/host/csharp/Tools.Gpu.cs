@@ -1,10 +1,11 @@
 // Tools.Gpu.cs -- the Tools statics on the hot path, as a drop-in: add `partial` to the declaration in
-// vtkPointCloud/BaseClass/Tools.cs:11 (`partial class Tools`), delete the five originals named below from that file
+// vtkPointCloud/BaseClass/Tools.cs:11 (`partial class Tools`), delete the six originals named below from that file
 // (same names, same signatures, same in-place effects) and add this file to the project.  Nothing else in Tools.cs
 // changes; the callers (FrmMain.cs:1533, Clustering.cs:125-181, SureDistanceFilter.cs:74, FrmMain.cs:1539-1540) stay
 // as they are.
 using System;
 using System.Collections.Generic;
+using System.Linq;
 
 namespace vtkPointCloud
 {
@@ -28,7 +29,8 @@ namespace vtkPointCloud
             if (K == 0 || n == 0) return;
             double[] c3 = new double[3 * K], c2 = new double[2 * K];
             long[] cnt = new long[K];
-            VcpNative.Check(VcpNative.vcp_centroids(VcpNative.Ctx, xyz, mot, lab, n, K, c3, c2, cnt));
+            using (VcpNative.Lease c = VcpNative.Rent())
+                VcpNative.Check(c, VcpNative.vcp_centroids(c.Ctx, xyz, mot, lab, n, K, c3, c2, cnt));
             for (int k = 0; k < K; k++)
             {
                 if (cnt[k] == 0) continue;
@@ -52,9 +54,61 @@ namespace vtkPointCloud
                 cxy[2 * k] = p.X; cxy[2 * k + 1] = p.Y; ids[k] = p.IDBeforeMerge;
             }
             int mergeCount;
-            VcpNative.Check(VcpNative.vcp_merge_centroids(VcpNative.Ctx, cxy, ids, K, thre, mapTo, out mergeCount));
+            using (VcpNative.Lease c = VcpNative.Rent())
+                VcpNative.Check(c, VcpNative.vcp_merge_centroids(c.Ctx, cxy, ids, K, thre, mapTo, out mergeCount));
             for (int k = 0; k < K; k++) if (mapTo[k] != 0) dick.Add(ids[k], mapTo[k]);
             return dick;
+        }
+
+        // Tools.refreshCensAndClusByDictionary, Tools.cs:521-572 (caller Clustering.cs:125-181): the points of every list
+        // whose id is a key of dic move to the END of list dic[id] (in clusList order), the merged lists go, the rest
+        // is renumbered 1..K' by ascending id and every centroid is recomputed.  List surgery stays here (it is the
+        // caller-visible structure); relabelling + renumbering + the K' x 5 means are one native call.
+        static public void refreshCensAndClusByDictionary(Dictionary<int, int> dic, List<ClusObj> clusList,
+                                                          ref List<Point3D> centers, ref List<Point3D> centers2D)
+        {
+            int K0 = clusList.Count;
+            // like the C#, a target is addressed by POSITION dic[id] - 1 (clusList[k].clusId == k + 1 on entry, Tools.cs:531)
+            foreach (ClusObj ob in clusList.ToArray())
+                if (dic.ContainsKey(ob.clusId)) clusList[dic[ob.clusId] - 1].li.AddRange(ob.li);
+            clusList.RemoveAll(delegate(ClusObj o) { return dic.ContainsKey(o.clusId); });
+            clusList.Sort(delegate(ClusObj a, ClusObj b) { return a.clusId.CompareTo(b.clusId); });   // ids are distinct
+            int n = 0, K = 0;
+            foreach (ClusObj ob in clusList) { n += ob.li.Count; K = Math.Max(K, ob.clusId); }
+            K = Math.Max(K, K0);
+            double[] xyz = new double[3 * Math.Max(n, 1)], mot = new double[2 * Math.Max(n, 1)];
+            int[] lab = new int[Math.Max(n, 1)], mapById = new int[Math.Max(K, 1)];   // the moves are done: identity map
+            int t = 0;
+            foreach (ClusObj ob in clusList)
+                foreach (Point3D p in ob.li)
+                {
+                    xyz[3 * t] = p.X; xyz[3 * t + 1] = p.Y; xyz[3 * t + 2] = p.Z;
+                    mot[2 * t] = p.motor_x; mot[2 * t + 1] = p.motor_y;
+                    lab[t++] = ob.clusId;
+                }
+            int newK = 0;
+            double[] c3 = new double[3 * Math.Max(K, 1)], c2 = new double[2 * Math.Max(K, 1)];
+            long[] cnt = new long[Math.Max(K, 1)];
+            if (n > 0)
+                using (VcpNative.Lease c = VcpNative.Rent())
+                    VcpNative.Check(c, VcpNative.vcp_refresh_by_dictionary(c.Ctx, xyz, mot, lab, n, K, mapById, out newK, c3, c2, cnt));
+            // surviving ids in ascending order take 1..K' (:551-560).  A surviving list WITHOUT points keeps its number in
+            // the C# too (idForMerge counts lists, the native call counts ids that still have points): number by position
+            int idForMerge = 0, k = 0;
+            t = 0;
+            foreach (ClusObj ob in clusList)
+            {
+                ob.clusId = ++idForMerge;
+                foreach (Point3D pp in ob.li) pp.clusterId = idForMerge;
+                if (ob.li.Count == 0)
+                {   // obj.li.Average on an empty list throws InvalidOperationException in the C# (:563)
+                    throw new InvalidOperationException("Sequence contains no elements");
+                }
+                centers.Add(new Point3D(c3[3 * k], c3[3 * k + 1], c3[3 * k + 2], ob.clusId, true));
+                centers2D.Add(new Point3D(c2[2 * k], c2[2 * k + 1], 0, ob.clusId, true));
+                k++;
+            }
+            Console.WriteLine("keys中包含" + dic.Count + "质心有" + centers.Count);
         }
 
         // Tools.getFixedPtsCentroid, Tools.cs:78-111 (caller SureDistanceFilter.cs:74)
@@ -76,7 +130,8 @@ namespace vtkPointCloud
             double[] c3 = new double[3 * K];
             long[] inside = new long[K];
             // an empty list: VCP_ERR_INDEX, where the C# throws ArgumentOutOfRangeException at li[0] (:106)
-            VcpNative.Check(VcpNative.vcp_centroids_weighted(VcpNative.Ctx, xyz, group, cid, cnt, n, K,
+            using (VcpNative.Lease c = VcpNative.Rent())
+                VcpNative.Check(c, VcpNative.vcp_centroids_weighted(c.Ctx, xyz, group, cid, cnt, n, K,
                 isIgnoreDuplication ? 1 : 0, c3, inside));
             for (int i = 0; i < K; i++)
             {
@@ -106,7 +161,8 @@ namespace vtkPointCloud
                 }
             double[] cen = new double[2 * K], rad = new double[K];
             byte[] valid = new byte[K];
-            VcpNative.Check(VcpNative.vcp_mcc(VcpNative.Ctx, xy, lab, null, n, n, K, cen, rad, valid, null));
+            using (VcpNative.Lease c = VcpNative.Rent())
+                VcpNative.Check(c, VcpNative.vcp_mcc(c.Ctx, xy, lab, null, n, n, K, cen, rad, valid, null));
             for (int j = 0; j < K; j++)
             {
                 if (valid[j] == 0) continue;   // li.Count <= 3 (:400)
@@ -135,7 +191,8 @@ namespace vtkPointCloud
             int[] lab = new int[n], blk = new int[n];
             long[] order = new long[Math.Max(n, 1)];
             long m, ev; int rows, cols, kept, del;
-            VcpNative.Check(VcpNative.vcp_dbscan_blocks_keyed(VcpNative.Ctx, key, mot, n, tr, pts, ptsInCell, 3, lab, blk,
+            using (VcpNative.Lease c = VcpNative.Rent())
+                VcpNative.Check(c, VcpNative.vcp_dbscan_blocks_keyed(c.Ctx, key, mot, n, tr, pts, ptsInCell, 3, lab, blk,
                 order, out m, out rows, out cols, out kept, out del, out clusterAmount, out ev));
             for (int i = 0; i < n; i++) { rawData[i].clusterId = lab[i]; rawData[i].isClassed = lab[i] != 0; }
             List<Point3D> clusForMerge = new List<Point3D>((int)m);

@@ -115,24 +115,68 @@ namespace vtkPointCloud
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_slab_finish(IntPtr ctx, uint[] map_rep, uint[] map_k, long n_tab,
             int[] tab_gid, uint[] tab_seed, uint own_lo, uint own_count, IntPtr d_labels, IntPtr d_is_classed, out long twice);
 
-        // one context per thread: StartCode runs on ThreadPool threads (FrmMain.cs:1358)
-        [ThreadStatic] static IntPtr tlsCtx;
-        public static IntPtr Ctx
+        // ---- contexts ---------------------------------------------------------------------------------------------
+        // A context (stream + device workspace, ~100 bytes per point of its largest call) serves one call at a time.
+        // StartCode runs on ThreadPool threads (FrmMain.cs:1358), which come and go: a context per thread would leak one
+        // context and its workspace per retired thread.  Callers therefore RENT a context for the duration of a call --
+        //     using (VcpNative.Lease c = VcpNative.Rent()) VcpNative.Check(c, VcpNative.vcp_dbscan(c.Ctx, ...));
+        // -- and Dispose returns it to a per-device pool; at most MaxPooled idle contexts are kept per device, the rest
+        // are destroyed on return.  Device selects the HIP ordinal new leases use (default 0); Shutdown() destroys
+        // every idle context (call it from Application.ApplicationExit).
+        public static int Device = 0;
+        public static int MaxPooled = 4;
+        static readonly object poolLock = new object();
+        static readonly System.Collections.Generic.Dictionary<int, System.Collections.Generic.Stack<IntPtr>> pool =
+            new System.Collections.Generic.Dictionary<int, System.Collections.Generic.Stack<IntPtr>>();
+
+        public sealed class Lease : IDisposable
         {
-            get
+            public IntPtr Ctx;
+            public readonly int DeviceId;
+            internal Lease(IntPtr c, int dev) { Ctx = c; DeviceId = dev; }
+            public void Dispose()
             {
-                if (tlsCtx == IntPtr.Zero)
+                IntPtr c = Ctx;
+                Ctx = IntPtr.Zero;
+                if (c == IntPtr.Zero) return;
+                lock (poolLock)
                 {
-                    if (IntPtr.Size != 8) throw new InvalidOperationException("libvcp is 64-bit only: build the host x64 / AnyCPU without Prefer32Bit");
-                    int rc = vcp_create(0, out tlsCtx);
-                    if (rc != 0) throw new InvalidOperationException("vcp_create: " + Marshal.PtrToStringAnsi(vcp_last_error(IntPtr.Zero)));
+                    System.Collections.Generic.Stack<IntPtr> st;
+                    if (!pool.TryGetValue(DeviceId, out st)) { st = new System.Collections.Generic.Stack<IntPtr>(); pool[DeviceId] = st; }
+                    if (st.Count < MaxPooled) { st.Push(c); return; }
                 }
-                return tlsCtx;
+                vcp_destroy(c);   // the pool is full: this context and its workspace go
             }
         }
-        public static void Check(int rc)
+
+        public static Lease Rent() { return Rent(Device); }
+        public static Lease Rent(int device)
         {
-            if (rc != 0) throw new InvalidOperationException("vcp error " + rc + ": " + Marshal.PtrToStringAnsi(vcp_last_error(tlsCtx)));
+            if (IntPtr.Size != 8) throw new InvalidOperationException("libvcp is 64-bit only: build the host x64 / AnyCPU without Prefer32Bit");
+            lock (poolLock)
+            {
+                System.Collections.Generic.Stack<IntPtr> st;
+                if (pool.TryGetValue(device, out st) && st.Count > 0) return new Lease(st.Pop(), device);
+            }
+            IntPtr c;
+            int rc = vcp_create(device, out c);
+            if (rc != 0) throw new InvalidOperationException("vcp_create(" + device + "): " + Marshal.PtrToStringAnsi(vcp_last_error(IntPtr.Zero)));
+            return new Lease(c, device);
+        }
+
+        public static void Shutdown()
+        {
+            lock (poolLock)
+            {
+                foreach (System.Collections.Generic.Stack<IntPtr> st in pool.Values)
+                    while (st.Count > 0) vcp_destroy(st.Pop());
+                pool.Clear();
+            }
+        }
+
+        public static void Check(Lease c, int rc)
+        {
+            if (rc != 0) throw new InvalidOperationException("vcp error " + rc + ": " + Marshal.PtrToStringAnsi(vcp_last_error(c.Ctx)));
         }
     }
 }

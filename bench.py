@@ -273,8 +273,11 @@ def roofline_of(avg, n_points, dim, metric_name):
         except Exception:
             traffic = None
     return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_point": bpp,
-            "kernel_ms": avg[dom]}
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": "profiles/pmc_latest.json: 2 x FETCH_SIZE + WRITE_SIZE of this phase's kernels from separate "
+                              "rocprofv3 --pmc passes of the same command on an earlier run (tools/profile.sh); NOT "
+                              "measured in this run" if traffic is not None else None,
+            "algorithmic_bytes_per_point": bpp, "kernel_ms": avg[dom]}
 
 
 def main():
@@ -547,6 +550,35 @@ def main():
             e = time.perf_counter() - t1
             best = e if best is None else min(best, e)
         out["monolithic_dbscan"] = {"ms": best * 1e3, "Mpoints_per_s": n / best / 1e6, "eps": eps, "min_pts": min_pts}
+    if extras and mode == "single" and metric_id == N.L1_2D:
+        # Beside the headline (a sparse, 2^-10-quantised cloud: 0.2 expected neighbours for the background half, and no
+        # pair the binary32 screen cannot decide): the same 10 M points at denser settings, an unquantised copy (the
+        # exact binary64 re-test of undecided pairs runs), and the Euclidean 3-D form.  Best of three, resident.
+        def best_of(ptr, d, e, mp, met, reps=3):
+            b, cfx = None, 0
+            for _ in range(reps):
+                t1 = time.perf_counter()
+                cfx, _ev = ctx.dbscan_dev(ptr, n, d, e, mp, met, 0, None, d_labels.data_ptr(), d_core.data_ptr(),
+                                          d_cls.data_ptr())
+                el = time.perf_counter() - t1
+                b = el if b is None else min(b, el)
+            return {"ms": b * 1e3, "Mpoints_per_s": n / b / 1e6, "clusters": int(cfx), "eps": e, "min_pts": mp}
+        beside = {}
+        dens = n / 2 / cloud["motor_extent"] ** 2  # background points per unit area
+        for tag, e in (("dense_eps0.3", 0.3), ("dense_eps0.7", 0.7)):
+            beside[tag] = dict(best_of(d_coords.data_ptr(), 2, e, min_pts, N.L1_2D),
+                               background_neighbours_expected=2.0 * e * e * dens)
+        jit = (synth.uniform01(977, 0, 2 * n).reshape(n, 2) - 0.5) * 2.0 ** -10  # real-valued: off the 2^-10 lattice
+        d_unq = torch.from_numpy(coords + jit).to(dev)
+        beside["unquantised"] = best_of(d_unq.data_ptr(), 2, eps, min_pts, N.L1_2D)
+        del d_unq
+        d_xyz3 = torch.from_numpy(cloud["xyz"]).to(dev)
+        beside["L2_3D"] = best_of(d_xyz3.data_ptr(), 3, cloud["eps_l2"], min_pts, N.L2_3D)
+        del d_xyz3
+        out["beside_headline"] = beside
+        # leave d_labels as the headline call left them (the centroid step below reads them)
+        ctx.dbscan_dev(d_coords.data_ptr(), n, dim, eps, min_pts, metric_id, 0, None, d_labels.data_ptr(),
+                       d_core.data_ptr(), d_cls.data_ptr())
     if extras and mode == "single":
         icp = {}
         for tag, jit, tol, rule, iters in (("c3_50_rounds_jitter0.05", 0.05, 0.0, N.STOP_SSE_DELTA, 50),

@@ -51,7 +51,7 @@ enum vcp_status {
 };
 
 /* -- context ------------------------------------------------------------------------------ */
-/* device_id: HIP ordinal (one context drives one GPU; multi-GPU = one process per GPU). */
+/* device_id: HIP ordinal (one context drives one GPU; several GPUs: vcp_create_multi below, or one process per GPU). */
 int vcp_create(int device_id, vcp_ctx** out);
 void vcp_destroy(vcp_ctx* ctx);
 const char* vcp_last_error(const vcp_ctx* ctx); /* ctx may be NULL: last create error      */
@@ -180,6 +180,31 @@ int vcp_blocks_finish_dev(vcp_ctx* ctx, const int32_t* d_local, int64_t evals_bl
                           int32_t* d_labels, int32_t* d_block_of, int64_t* d_merge_order,
                           int64_t* m_out, int32_t* kept, int32_t* del_sum, int32_t* cluster_amount,
                           int64_t* dist_evals);
+
+/* -- several GPUs from ONE process -----------------------------------------------------------
+ * The reference fans its blocks out from one process (ThreadPool.QueueUserWorkItem(StartCode, cells[i]) per block,
+ * FrmMain.cs:1356-1359) and merges on the UI thread (CompleteWork3, :1442-1520).  vcp_multi is the drop-in form of
+ * that for a host that owns several GPUs: one vcp_ctx per listed HIP device (a device id may repeat: several contexts
+ * on one GPU), driven by one host thread each.  vcp_dbscan_blocks_multi = vcp_dbscan_blocks_keyed (key_xy may be NULL)
+ * with the per-block DBImproved step sharded over the devices by contiguous block ranges balanced on point count
+ * (vcp_blocks_share_plan); the block-major label slices travel to device 0 as peer copies over xGMI, device 0 runs
+ * CompleteWork3.  Results are identical to the one-device call, bit for bit.  (The multi-PROCESS form -- one rank per
+ * GPU, ONE RCCL all-gather -- is vtkcloudpoint_amd/distributed.py: sharded_blocks, over the staged entry points.) */
+typedef struct vcp_multi vcp_multi;
+int vcp_create_multi(const int* device_ids, int n, vcp_multi** out);
+void vcp_destroy_multi(vcp_multi* m);
+const char* vcp_multi_last_error(const vcp_multi* m); /* m may be NULL: last create error */
+int vcp_multi_count(const vcp_multi* m);
+vcp_ctx* vcp_multi_ctx(vcp_multi* m, int i);          /* borrowed: context of device i for single-GPU calls */
+int vcp_dbscan_blocks_multi(vcp_multi* m, const double* key_xy, const double* motor, int64_t n, double eps, int min_pts,
+                            int pts_in_cell, int small_max, int32_t* labels, int32_t* block_of, int64_t* merge_order,
+                            int64_t* m_out, int32_t* rows, int32_t* cols, int32_t* kept, int32_t* del_sum,
+                            int32_t* cluster_amount, int64_t* dist_evals);
+/* The range arithmetic of vcp_blocks_share and vcp_dbscan_blocks_multi as a pure host function (no device, no
+ * context): blockstart [nblocks + 1] = first block-major position of every block (ascending, blockstart[nblocks] = m);
+ * cuts [world + 1] <- first block of every rank (cuts[0] = 0, cuts[world] = nblocks): rank r starts at the first block
+ * whose first position is >= m * r / world. */
+int vcp_blocks_share_plan(const uint32_t* blockstart, int64_t nblocks, int world, int64_t* cuts);
 
 /* -- exact DBSCAN over several GPUs (SURVEY.md 8e mode 2) -----------------------------------
  * One monolithic DBImproved.dbscan (BC/DBImproved.cs:91-114) over a cloud that is spread over several

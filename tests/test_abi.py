@@ -84,3 +84,31 @@ def test_horn_step_cold_start_on_a_nan_or_garbage_basis():
         assert np.array_equal(Vb, Vc)             # the basis stored back is the cold start's
     Rw, Tw, _ = solve(Vc.reshape(4, 4), 1)        # a good basis: warm start, same answer to rounding
     assert np.allclose(Rw, R0, atol=1e-12) and np.allclose(Tw, T0, atol=1e-12)
+
+
+def test_block_range_plan_for_2_3_8_ranks():
+    """vcp_blocks_share_plan (host arithmetic behind vcp_blocks_share and vcp_dbscan_blocks_multi): contiguous ranges that
+    cover every block once, cut at the first block whose first position reaches m * r / world, balanced on points."""
+    import numpy as np
+    from vtkcloudpoint_amd import _native
+    rng = np.random.default_rng(11)
+    for trial in range(200):
+        nb = int(rng.integers(1, 400))
+        sizes = rng.integers(0, 50, nb)
+        if trial % 5 == 0:
+            sizes[rng.integers(0, nb)] = 5000  # one block that dwarfs the rest
+        if trial % 7 == 0:
+            sizes[:] = 0
+        bs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+        m = int(bs[-1])
+        for world in (1, 2, 3, 8):
+            cuts = _native.blocks_share_plan(bs, world)
+            assert cuts[0] == 0 and cuts[-1] == nb and np.all(np.diff(cuts) >= 0)
+            for r in range(1, world):
+                target = (m * r) // world
+                want = int(np.searchsorted(bs[:nb], target, side="left"))
+                assert cuts[r] == max(want, cuts[r - 1])
+            if m > 0 and sizes.max() > 0:
+                share = np.diff(bs[cuts].astype(np.int64))
+                assert share.sum() == m
+                assert share.max() <= m / world + sizes.max()  # never worse than one block over the fair share

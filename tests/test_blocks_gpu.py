@@ -150,3 +150,30 @@ def test_final_order_counting_sort_equals_library_sort(vcp_ctx, oracle):
             assert np.array_equal(g["labels"], o["labels"])
             assert np.array_equal(g["order"], o["order"])
             assert g["kept"] == o["kept"] and g["cluster_amount"] == o["cluster_amount"] and g["evals"] == o["evals"]
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_blocks_multi_from_one_process_equals_the_single_device_call(vcp_ctx, oracle, devices):
+    """vcp_dbscan_blocks_multi: one process drives one context (and one host thread) per listed device -- here the same
+    GPU listed one to three times, which exercises the device threads, the range plan and the peer copies of the label
+    slices; a box with several GPUs runs the same code with distinct ids (unmeasured on hardware).  Every output equals
+    the one-device call and the oracle, also with the partition on separate keys (getClusterFromList)."""
+    mc = N.MultiContext(devices)
+    assert mc.count() == len(devices)
+    d = synth.config_cloud(200_000, seed=21)
+    motor = d["motor"]
+    key = np.ascontiguousarray(d["xyz"][:, :2])
+    for kx in (None, key):
+        g1 = vcp_ctx.dbscan_blocks(motor, 0.07, 7, 200, 3, key_xy=kx)
+        gm = mc.dbscan_blocks(motor, 0.07, 7, 200, 3, key_xy=kx)
+        ob = oracle.block_pipeline(motor, 0.07, 7, 200, 3, key_xy=kx)
+        for k in ("labels", "block_of", "order"):
+            assert np.array_equal(gm[k], g1[k]), k
+            assert np.array_equal(gm[k], ob[k]), k
+        for k in ("rows", "cols", "kept", "del_sum", "cluster_amount", "evals"):
+            assert gm[k] == g1[k] == ob[k], k
+    # error behaviour like the single-device call: an empty list throws in the C# (FrmMain.cs:1224)
+    with pytest.raises(N.VcpError) as e:
+        mc.dbscan_blocks(np.zeros((0, 2)), 0.07, 7, 200, 3)
+    assert e.value.code == -2
+    mc.close()

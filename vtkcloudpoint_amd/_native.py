@@ -27,7 +27,8 @@ SYMBOLS = [
     "vcp_match", "vcp_mcc", "vcp_assign_truths", "vcp_icp_vtklike", "vcp_import_convert",
     "vcp_slab_begin", "vcp_slab_comps", "vcp_slab_finish", "vcp_release_workspace", "vcp_selftest_scan_dev",
     "vcp_centroids_weighted", "vcp_dbscan_blocks_keyed", "vcp_blocks_begin_keyed", "vcp_blocks_begin_keyed_dev",
-    "vcp_selftest_horn",
+    "vcp_selftest_horn", "vcp_create_multi", "vcp_destroy_multi", "vcp_multi_last_error", "vcp_multi_count",
+    "vcp_multi_ctx", "vcp_dbscan_blocks_multi", "vcp_blocks_share_plan",
 ]
 
 
@@ -60,6 +61,12 @@ def lib():
         _lib.vcp_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         _lib.vcp_destroy.argtypes = [C.c_void_p]
         _lib.vcp_destroy.restype = None
+        _lib.vcp_multi_last_error.restype = C.c_char_p
+        _lib.vcp_multi_last_error.argtypes = [C.c_void_p]
+        _lib.vcp_destroy_multi.argtypes = [C.c_void_p]
+        _lib.vcp_destroy_multi.restype = None
+        _lib.vcp_multi_ctx.restype = C.c_void_p
+        _lib.vcp_multi_ctx.argtypes = [C.c_void_p, C.c_int]
     return _lib
 
 
@@ -414,3 +421,58 @@ class Context:
                                            int(xdir), int(ydir), int(dedupe), _ptr(xyz), _ptr(state), C.byref(kept),
                                            C.byref(dup)))
         return dict(xyz=xyz, state=state, kept=kept.value, duplicates=dup.value)
+
+
+def blocks_share_plan(blockstart, world):
+    """vcp_blocks_share_plan: first block of every rank, [world + 1] (pure host arithmetic, no device)."""
+    bs = np.ascontiguousarray(blockstart, np.uint32)
+    cuts = np.zeros(int(world) + 1, np.int64)
+    rc = lib().vcp_blocks_share_plan(_ptr(bs), C.c_int64(len(bs) - 1), C.c_int(int(world)), _ptr(cuts))
+    if rc != 0:
+        raise VcpError(rc, "vcp_blocks_share_plan")
+    return cuts
+
+
+class MultiContext:
+    """vcp_multi: several GPUs driven from this one process (one vcp_ctx and one host thread per listed device; an id
+    may repeat).  dbscan_blocks = Context.dbscan_blocks with the per-block step sharded over the devices."""
+
+    def __init__(self, device_ids):
+        ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
+        self._h = C.c_void_p()
+        rc = lib().vcp_create_multi(ids, len(device_ids), C.byref(self._h))
+        if rc != 0:
+            raise VcpError(rc, (lib().vcp_multi_last_error(None) or b"").decode())
+
+    def close(self):
+        if self._h:
+            lib().vcp_destroy_multi(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def count(self):
+        return int(lib().vcp_multi_count(self._h))
+
+    def dbscan_blocks(self, motor, eps, min_pts, pts_in_cell, small_max=3, key_xy=None):
+        motor = _f64(motor, 2)
+        n = len(motor)
+        key_xy = None if key_xy is None else _f64(key_xy, 2)
+        labels = np.zeros(n, np.int32)
+        block_of = np.zeros(n, np.int32)
+        order = np.zeros(max(n, 1), np.int64)
+        m = C.c_int64(0)
+        rows, cols, kept, dels, ca = (C.c_int32(0) for _ in range(5))
+        ev = C.c_int64(0)
+        rc = lib().vcp_dbscan_blocks_multi(self._h, _ptr(key_xy), _ptr(motor), C.c_int64(n), C.c_double(eps), int(min_pts),
+                                           int(pts_in_cell), int(small_max), _ptr(labels), _ptr(block_of), _ptr(order),
+                                           C.byref(m), C.byref(rows), C.byref(cols), C.byref(kept), C.byref(dels),
+                                           C.byref(ca), C.byref(ev))
+        if rc != 0:
+            raise VcpError(rc, (lib().vcp_multi_last_error(self._h) or b"").decode())
+        return dict(labels=labels, block_of=block_of, order=order[: m.value].copy(), rows=rows.value, cols=cols.value,
+                    kept=kept.value, del_sum=dels.value, cluster_amount=ca.value, evals=ev.value)

@@ -956,16 +956,12 @@ int vcp_blocks_share(vcp_ctx* ctx, int rank, int world, int32_t* block_lo, int32
   BlocksState* s = ctx->blocks;
   if (!s || !s->ready) return vcp_fail(ctx, VCP_ERR_ARG, "vcp_blocks_begin has not run");
   if (world < 1 || rank < 0 || rank >= world) return vcp_fail(ctx, VCP_ERR_ARG, "rank/world");
-  // contiguous block ranges balanced on the point count: rank r starts at the first block whose first
-  // position is >= m*r/world
-  auto cut = [&](int r) -> int64_t {
-    if (r <= 0) return 0;
-    if (r >= world) return s->nblocks;
-    uint32_t target = (uint32_t)((s->m * (int64_t)r) / world);
-    auto it = std::lower_bound(s->h_blockstart.begin(), s->h_blockstart.begin() + s->nblocks, target);
-    return (int64_t)(it - s->h_blockstart.begin());
-  };
-  int64_t lo = cut(rank), hi = cut(rank + 1);
+  // contiguous block ranges balanced on the point count (vcp_blocks_share_plan, multi.hip: the same arithmetic for the
+  // multi-process ranks and for the device threads of vcp_dbscan_blocks_multi)
+  std::vector<int64_t> cuts((size_t)world + 1);
+  if (vcp_blocks_share_plan(s->h_blockstart.data(), s->nblocks, world, cuts.data()) != VCP_OK)
+    return vcp_fail(ctx, VCP_ERR_ARG, "share plan");
+  const int64_t lo = cuts[(size_t)rank], hi = cuts[(size_t)rank + 1];
   if (block_lo) *block_lo = (int32_t)lo;
   if (block_hi) *block_hi = (int32_t)hi;
   if (pos_lo) *pos_lo = s->h_blockstart[(size_t)lo];

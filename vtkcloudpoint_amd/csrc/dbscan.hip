@@ -34,8 +34,6 @@
 #include <limits>
 #include <vector>
 
-#include <rocprim/rocprim.hpp>
-
 #include "dbscan_engine.hpp"
 #include "grid_common.hpp"
 
@@ -240,117 +238,11 @@ __global__ __launch_bounds__(TPB) void k_moments(const double* __restrict__ c, i
   }
 }
 
-// ---- sort-based grid build ---------------------------------------------------------------------------
-// Global atomics execute at the memory side on this part (about 20 G scattered adds/s chip-wide), so a
-// histogram with one returned atomic per point costs more than a radix sort of (cell id, point index) pairs,
-// whose counting happens in LDS.  The sort also makes the scatter a gather: reads are random, stores coalesced.
-template <int GD, bool GROUPED>
-__global__ __launch_bounds__(TPB) void k_cell_key(const double* __restrict__ c, int64_t n, int stride, GridP g,
-                                                 const int32_t* __restrict__ group, int glo, int ghi,
-                                                 uint32_t* __restrict__ key, uint32_t* __restrict__ val,
-                                                 uint32_t* __restrict__ pos) {
-  int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
-  if (i >= n) return;
-  val[i] = (uint32_t)i;
-  if (GROUPED) {
-    int gg = group[i];
-    if (gg < glo || gg >= ghi) {
-      key[i] = g.ncells;  // excluded from this call: sorts behind every cell
-      pos[i] = NONE;
-      return;
-    }
-  }
-  double q[3];
-  int cc[3];
-  load_in<GD>(c, i, stride, q);
-  key[i] = cell_of<GD>(q, g, cc);
-}
-
-// Cell starts from the sorted keys, tile by tile.  The table has ~5 entries per point on sparse clouds, so it is
-// written exactly once and never zero-filled or scanned in global memory: the keys of a tile of CTILE consecutive
-// cells are counted in LDS, scanned there, and the tile's slice of the table is stored coalesced.  Which keys
-// belong to a tile comes from marks of the tile ends in the key list + a max-scan over the (few) tiles.
-constexpr int CTILE = 8192;
-__global__ __launch_bounds__(TPB) void k_tile_marks(const uint32_t* __restrict__ skey, int64_t n, uint32_t* __restrict__ tmark) {
-  int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
-  if (p >= n) return;
-  const uint32_t t = skey[p] / CTILE;
-  if (p == n - 1 || skey[p + 1] / CTILE != t) tmark[t] = (uint32_t)p + 1u;
-}
-__global__ __launch_bounds__(TPB) void k_cellstart_tiles(const uint32_t* __restrict__ skey, const uint32_t* __restrict__ tilestart,
-                                                        uint32_t ncells, uint32_t* __restrict__ cellstart) {
-  // one pad word per 32 counters: a thread's run of 32 consecutive counters then walks all banks
-  __shared__ uint32_t cnt[CTILE + CTILE / 32];
-  __shared__ uint32_t wsum[TPB / 64];
-  auto at = [](int i) { return i + (i >> 5); };
-  const uint32_t c0 = blockIdx.x * (uint32_t)CTILE;
-  const uint32_t p_lo = tilestart[blockIdx.x], p_hi = tilestart[blockIdx.x + 1];
-  for (int k = threadIdx.x; k < CTILE + CTILE / 32; k += TPB) cnt[k] = 0;
-  __syncthreads();
-  for (uint32_t p = p_lo + threadIdx.x; p < p_hi; p += TPB) atomicAdd(&cnt[at((int)(skey[p] - c0))], 1u);
-  __syncthreads();
-  // exclusive scan of the CTILE counters: thread t owns CTILE / TPB consecutive ones
-  constexpr int PER = CTILE / TPB;
-  const int base = threadIdx.x * PER;
-  uint32_t loc = 0;
-#pragma unroll 8
-  for (int k = 0; k < PER; k++) loc += cnt[at(base + k)];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  uint32_t inc = loc;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t t = __shfl_up(inc, d, 64);
-    if (lane >= d) inc += t;
-  }
-  if (lane == 63) wsum[w] = inc;
-  __syncthreads();
-  uint32_t pre = p_lo + inc - loc;
-  for (int k = 0; k < w; k++) pre += wsum[k];
-#pragma unroll 8
-  for (int k = 0; k < PER; k++) {
-    const uint32_t v = cnt[at(base + k)];
-    cnt[at(base + k)] = pre;
-    pre += v;
-  }
-  __syncthreads();
-  // coalesced store; cells up to and including index ncells (= number of included points) exist in the table
-  for (int k = threadIdx.x; k < CTILE; k += TPB)
-    if (c0 + (uint32_t)k <= ncells) cellstart[c0 + k] = cnt[at(k)];
-}
-
-template <int GD, bool GROUPED>
-__global__ __launch_bounds__(TPB) void k_gather(const double* __restrict__ c, int stride,
-                                               const uint32_t* __restrict__ cellstart, uint32_t ncells,
-                                               const uint32_t* __restrict__ sidx, const uint8_t* __restrict__ in_classed,
-                                               const int32_t* __restrict__ group, const uint32_t* __restrict__ ord,
-                                               uint32_t* __restrict__ pos, double* __restrict__ sorted,
-                                               uint32_t* __restrict__ sord, int32_t* __restrict__ sgroup,
-                                               uint8_t* __restrict__ flags, float* __restrict__ sorted32, GridP g) {
-  const uint32_t nin = cellstart[ncells];
-  int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
-  if (p >= nin) return;
-  const uint32_t i = sidx[p];
-  pos[i] = (uint32_t)p;
-  double q[3];
-  load_in<GD>(c, i, stride, q);
-  if (GD == 2) {
-    *reinterpret_cast<double2*>(sorted + 2 * p) = make_double2(q[0], q[1]);
-  } else {
-    sorted[3 * p] = q[0];
-    sorted[3 * p + 1] = q[1];
-    sorted[3 * p + 2] = q[2];
-  }
-  store_pt32<GD>(sorted32, p, q, g);
-  if (ord) sord[p] = ord[i];  // otherwise sidx IS sord (the sort wrote it there)
-  if (GROUPED) sgroup[p] = group[i];
-  if (in_classed) flags[p] = in_classed[i] ? F_CLASSED : 0;  // otherwise flags were zero-filled
-}
-
 // iterate the candidate rows of a cell neighbourhood: f(s, e) for the position range of each of the 3 (9)
 // x-rows, in increasing position order; f returns false to stop early.  All row bounds are fetched up front
 // (6 or 18 independent cellstart loads in flight) instead of two dependent loads per row.
 template <int GD, class F>
-__device__ __forceinline__ void for_rows(const int* cc, const GridP& g, const uint32_t* __restrict__ cellstart, F&& f) {
+__device__ __forceinline__ void for_rows(const int* cc, const GridP& g, const CellTab& ct, F&& f) {
   constexpr int NR = GD == 3 ? 9 : 3;
   const int x0 = max(cc[0] - 1, 0), x1 = min(cc[0] + 1, g.D[0] - 1);
   uint32_t rs[NR], re[NR];
@@ -360,8 +252,8 @@ __device__ __forceinline__ void for_rows(const int* cc, const GridP& g, const ui
     const int z = GD == 3 ? cc[2] + (r / 3) - 1 : 0;
     const bool ok = y >= 0 && y < g.D[1] && (GD != 3 || (z >= 0 && z < g.D[2]));
     const uint32_t base = ok ? cell_id<GD>(g, 0, y, z) : 0u;
-    rs[r] = ok ? cellstart[base + x0] : 0u;
-    re[r] = ok ? cellstart[base + x1 + 1] : 0u;
+    rs[r] = ok ? ct_start(ct, base + x0) : 0u;
+    re[r] = ok ? ct_start(ct, base + x1 + 1) : 0u;
   }
   for (int r = 0; r < NR; r++)
     if (rs[r] < re[r])
@@ -371,8 +263,7 @@ __device__ __forceinline__ void for_rows(const int* cc, const GridP& g, const ui
 // the same bounds as plain arrays, for kernels that keep per-lane state across rows (a loop body that is not
 // a lambda keeps that state in registers)
 template <int GD>
-__device__ __forceinline__ void row_bounds(const int* cc, const GridP& g, const uint32_t* __restrict__ cellstart,
-                                           uint32_t* rs, uint32_t* re) {
+__device__ __forceinline__ void row_bounds(const int* cc, const GridP& g, const CellTab& ct, uint32_t* rs, uint32_t* re) {
   constexpr int NR = GD == 3 ? 9 : 3;
   const int x0 = max(cc[0] - 1, 0), x1 = min(cc[0] + 1, g.D[0] - 1);
 #pragma unroll
@@ -381,8 +272,8 @@ __device__ __forceinline__ void row_bounds(const int* cc, const GridP& g, const 
     const int z = GD == 3 ? cc[2] + (r / 3) - 1 : 0;
     const bool ok = y >= 0 && y < g.D[1] && (GD != 3 || (z >= 0 && z < g.D[2]));
     const uint32_t base = ok ? cell_id<GD>(g, 0, y, z) : 0u;
-    rs[r] = ok ? cellstart[base + x0] : 0u;
-    re[r] = ok ? cellstart[base + x1 + 1] : 0u;
+    rs[r] = ok ? ct_start(ct, base + x0) : 0u;
+    re[r] = ok ? ct_start(ct, base + x1 + 1) : 0u;
   }
 }
 
@@ -452,8 +343,7 @@ __device__ __forceinline__ void wl_count(bool isE, bool isB, uint32_t blk, uint3
 }
 
 // fill both lists from the flags, in position order
-__global__ __launch_bounds__(TPB) void k_wl_fill(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ cellstart,
-                                                uint32_t ncells, const uint32_t* __restrict__ scanE,
+__global__ __launch_bounds__(TPB) void k_wl_fill(const uint8_t* __restrict__ flags, CellTab ct, const uint32_t* __restrict__ scanE,
                                                 const uint32_t* __restrict__ scanB, uint32_t* __restrict__ listE,
                                                 uint32_t* __restrict__ listB, uint32_t* __restrict__ seedflag, uint32_t nw,
                                                 unsigned long long* __restrict__ counters) {
@@ -467,7 +357,7 @@ __global__ __launch_bounds__(TPB) void k_wl_fill(const uint8_t* __restrict__ fla
     for (uint32_t wd = gridDim.x * 8u + threadIdx.x; wd < nw; wd += TPB) seedflag[wd] = 0u;
     if (threadIdx.x < 68) counters[threadIdx.x] = 0ull;
   }
-  const uint32_t nin = cellstart[ncells];
+  const uint32_t nin = *ct.nin;
   const int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
   const uint8_t fl = p < nin ? flags[p] : 0;
   const bool isE = fl & F_EXPAND, isB = fl & F_BCAND;
@@ -537,13 +427,13 @@ __device__ __forceinline__ void nbr_flush(const NbrOut& no, const uint32_t* lnb,
 
 template <int GD, int METRIC, bool GROUPED>
 __global__ __launch_bounds__(TPB) void k_core(ExactSrc xs, GridP g, double thr, int min_pts,
-                                             const uint32_t* __restrict__ cellstart,
+                                             CellTab ct,
                                              const int32_t* __restrict__ sgroup, uint8_t* __restrict__ flags,
                                              uint32_t* __restrict__ parent, uint32_t* __restrict__ minord,
                                              uint32_t* __restrict__ blkE, uint32_t* __restrict__ blkB, NbrOut no,
                                              const float* __restrict__ sorted32, Screen sc, bool has_cls) {
   extern __shared__ uint32_t lnb[];  // [NB * TPB] staged lists, then [NB * TPB] for their compaction
-  const uint32_t nin = cellstart[g.ncells];
+  const uint32_t nin = *ct.nin;
   const int64_t blk = xcd_block(gridDim.x);
   int64_t p = blk * TPB + threadIdx.x;
   const bool live = p < nin;
@@ -557,7 +447,7 @@ __global__ __launch_bounds__(TPB) void k_core(ExactSrc xs, GridP g, double thr, 
   const int32_t myg = (GROUPED && live) ? sgroup[p] : 0;
   int cnt = 0, nrec = 0;
   const int NB = no.NB;
-  if (live) for_rows<GD>(cc, g, cellstart, [&](uint32_t s, uint32_t e) {
+  if (live) for_rows<GD>(cc, g, ct, [&](uint32_t s, uint32_t e) {
     // batches of UNR candidates: UNR independent loads in flight per lane (the loop is latency bound), the
     // early exit is checked once per batch.  Candidates are screened on their binary32 copies (within_scr).
     for (uint32_t j = s; j < e; j += UNR) {
@@ -638,14 +528,14 @@ struct CoreTile<2> {  // 3 rows x 512 x 8 B = 12 KB (+ slack: a lane's last trip
 // returns true when every range fits the tile (uniform over the workgroup)
 template <int GD>
 __device__ __forceinline__ bool tile_bounds(CoreTile<GD>& t, bool live, const int* cc, const GridP& g,
-                                            const uint32_t* __restrict__ cellstart, uint32_t* rs, uint32_t* re) {
+                                            const CellTab& ct, uint32_t* rs, uint32_t* re) {
   constexpr int NR = CoreTile<GD>::NR;
   if (threadIdx.x < NR) {
     t.lo[threadIdx.x] = NONE;
     t.hi[threadIdx.x] = 0u;
   }
   if (live) {
-    row_bounds<GD>(cc, g, cellstart, rs, re);
+    row_bounds<GD>(cc, g, ct, rs, re);
   } else {
 #pragma unroll
     for (int r = 0; r < NR; r++) rs[r] = re[r] = 0u;
@@ -716,7 +606,8 @@ __device__ __forceinline__ void nbr_flush_masks(const NbrOut& no, uint32_t* lout
   if (rescan) {
     double q[3];
     load_exact<GD>(xs, (uint32_t)p, q);
-    for (int r = 0; r < NR; r++)
+#pragma unroll
+    for (int r = 0; r < NR; r++)  // (unrolled: rs / re stay in registers -- a runtime index would put them in scratch)
       for (uint32_t j = rs[r]; j < re[r] && k < nrec; j++) {
         double rr[3];
         load_exact<GD>(xs, j, rr);
@@ -740,14 +631,14 @@ __device__ __forceinline__ void nbr_flush_masks(const NbrOut& no, uint32_t* lout
 
 template <int GD, int METRIC>
 __global__ __launch_bounds__(TPB) void k_core_lds(ExactSrc xs, GridP g, double thr, int min_pts,
-                                                 const uint32_t* __restrict__ cellstart, uint8_t* __restrict__ flags,
+                                                 CellTab ct, uint8_t* __restrict__ flags,
                                                  uint32_t* __restrict__ parent, uint32_t* __restrict__ minord,
                                                  uint32_t* __restrict__ blkE, uint32_t* __restrict__ blkB, NbrOut no,
                                                  const float* __restrict__ sorted32, Screen sc, bool has_cls) {
   constexpr int NR = CoreTile<GD>::NR;
   constexpr int OWN = NR / 2;  // the row of the point's own cell (dy = dz = 0)
   __shared__ CoreTile<GD> t;
-  const uint32_t nin = cellstart[g.ncells];
+  const uint32_t nin = *ct.nin;
   const int64_t blk = xcd_block(gridDim.x);
   int64_t p = blk * TPB + threadIdx.x;
   const bool live = p < nin;
@@ -758,7 +649,7 @@ __global__ __launch_bounds__(TPB) void k_core_lds(ExactSrc xs, GridP g, double t
     cell_of32<GD>(qf, g, cc);
   }
   uint32_t rs[NR], re[NR];
-  const bool fits = tile_bounds<GD>(t, live, cc, g, cellstart, rs, re);
+  const bool fits = tile_bounds<GD>(t, live, cc, g, ct, rs, re);
   constexpr int UNR = 4;  // hit nibbles
   int cnt = 0;
   // per row a bit mask of which of the lane's first 32 candidates were hits (two extra VALU operations per candidate;
@@ -921,7 +812,7 @@ __device__ __forceinline__ uint32_t uf_link(uint32_t* parent, uint32_t ra, uint3
 // stores, no atomics: each thread writes only its own parent and pointers only go down, so this is a forest.
 template <int GD, int METRIC, bool GROUPED>
 __global__ __launch_bounds__(TPB) void k_union_init(ExactSrc xs, GridP g, double thr,
-                                                   const uint32_t* __restrict__ cellstart,
+                                                   CellTab ct,
                                                    const int32_t* __restrict__ sgroup,
                                                    const uint8_t* __restrict__ flags, uint32_t* __restrict__ parent,
                                                    WorkList wlE, const float* __restrict__ sorted32, Screen sc) {
@@ -935,7 +826,7 @@ __global__ __launch_bounds__(TPB) void k_union_init(ExactSrc xs, GridP g, double
   const int32_t myg = GROUPED ? sgroup[p] : 0;
   const uint32_t me = (uint32_t)p;
   uint32_t first = me;
-  for_rows<GD>(cc, g, cellstart, [&](uint32_t s, uint32_t e) {
+  for_rows<GD>(cc, g, ct, [&](uint32_t s, uint32_t e) {
     if (s >= me) return true;  // only smaller positions (pointers must decrease); runs come in any order
     if (e > me) e = me;
     for (uint32_t j0 = s; j0 < e; j0 += UNR) {
@@ -1027,9 +918,9 @@ __global__ __launch_bounds__(TPB) void k_flatten0(uint32_t* __restrict__ parent,
 // DENSE_PER_CELL points per cell; sparse clouds (the benchmark clouds: 0.1 per cell) keep the plain loop.
 constexpr uint32_t CHUNK_MIXED = 0xFFFFFFFEu;
 constexpr int DENSE_PER_CELL = 16;
-__global__ __launch_bounds__(TPB) void k_chunkroot(const uint32_t* __restrict__ parent, const uint32_t* __restrict__ cellstart,
-                                                  uint32_t ncells, uint32_t* __restrict__ chunkroot) {
-  const uint32_t nin = cellstart[ncells];
+__global__ __launch_bounds__(TPB) void k_chunkroot(const uint32_t* __restrict__ parent, CellTab ct,
+                                                  uint32_t* __restrict__ chunkroot) {
+  const uint32_t nin = *ct.nin;
   const int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
   const uint32_t x = p < nin ? parent[p] : NONE;  // NONE = not expanding
   const unsigned long long have = __ballot(x != NONE);
@@ -1074,7 +965,7 @@ __global__ __launch_bounds__(TPB) void k_chunkroot(const uint32_t* __restrict__ 
 // measured: 282 us against 258 us -- the per-workgroup range reduction and barriers cost more than the L1 accesses saved.)
 template <int GD, int METRIC, bool GROUPED, bool PRE, bool DENSE = false>
 __global__ __launch_bounds__(TPB) void k_union(ExactSrc xs, GridP g, double thr,
-                                              const uint32_t* __restrict__ cellstart,
+                                              CellTab ct,
                                               const int32_t* __restrict__ sgroup, uint32_t* __restrict__ parent,
                                               WorkList wlE, const float* __restrict__ sorted32, Screen sc,
                                               const uint32_t* __restrict__ chunkroot = nullptr) {
@@ -1086,7 +977,7 @@ __global__ __launch_bounds__(TPB) void k_union(ExactSrc xs, GridP g, double thr,
   int cc[3];
   load_pt32<GD>(sorted32, p, qf);
   cell_of32<GD>(qf, g, cc);
-  row_bounds<GD>(cc, g, cellstart, rs, re);
+  row_bounds<GD>(cc, g, ct, rs, re);
   constexpr int UNR = PRE ? VCP_UNRW : (GD == 3 ? VCP_UNR3 : VCP_UNR2);
   const int32_t myg = GROUPED ? sgroup[p] : 0;
   const uint32_t me = (uint32_t)p;
@@ -1242,7 +1133,7 @@ __device__ __forceinline__ void twice_add(unsigned twice, unsigned long long* __
 // seed came up (BaseClass/DBImproved.cs:93-104 then :63-67)
 template <int GD, int METRIC, bool GROUPED>
 __global__ __launch_bounds__(TPB) void k_border(ExactSrc xs, GridP g, double thr,
-                                               const uint32_t* __restrict__ cellstart,
+                                               CellTab ct,
                                                const int32_t* __restrict__ sgroup, const uint8_t* __restrict__ flags,
                                                const uint32_t* __restrict__ parent, const uint32_t* __restrict__ sord,
                                                const uint32_t* __restrict__ rootk, const uint32_t* __restrict__ clseed,
@@ -1266,7 +1157,7 @@ __global__ __launch_bounds__(TPB) void k_border(ExactSrc xs, GridP g, double thr
       // among non-expanding points, and once some cluster is known to reach it, further members of clusters
       // ranked between the current min and max cannot change the result -- only the remaining candidates pay
       // for the coordinate load and the binary64 test.
-      for_rows<GD>(cc, g, cellstart, [&](uint32_t s, uint32_t e) {
+      for_rows<GD>(cc, g, ct, [&](uint32_t s, uint32_t e) {
         for (uint32_t j0 = s; j0 < e; j0 += UNR) {
           uint32_t rk[UNR];
 #pragma unroll
@@ -1333,8 +1224,8 @@ __global__ __launch_bounds__(TPB) void k_border_list(const int32_t* __restrict__
 // everything else (no neighbour within eps) keeps 0
 __global__ __launch_bounds__(TPB) void k_labk_rest(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ parent,
                                                   uint32_t* rootk, uint32_t* __restrict__ labk,
-                                                  const uint32_t* __restrict__ cellstart, uint32_t ncells) {
-  const uint32_t nin = cellstart[ncells];
+                                                  CellTab ct) {
+  const uint32_t nin = *ct.nin;
   int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
   if (p >= nin) return;
   const uint8_t fl = flags[p];
@@ -1488,9 +1379,9 @@ __global__ __launch_bounds__(TPB) void k_lonely_seeds(const double* __restrict__
 // the list of local components; it resolves them against the other ranks' and comes back with, per local
 // component, an index into a table of global clusters sorted by cluster id (vcp_slab_finish).
 __global__ __launch_bounds__(TPB) void k_slab_count(const uint32_t* __restrict__ parent, const uint8_t* __restrict__ flags,
-                                                   const uint32_t* __restrict__ cellstart, uint32_t ncells,
+                                                   CellTab ct,
                                                    uint32_t* __restrict__ blkcnt) {
-  const uint32_t nin = cellstart[ncells];
+  const uint32_t nin = *ct.nin;
   int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
   const bool root = p < nin && (flags[p] & F_EXPAND) && parent[p] == (uint32_t)p;
   __shared__ unsigned wc[TPB / 64];
@@ -1506,9 +1397,9 @@ __global__ __launch_bounds__(TPB) void k_slab_count(const uint32_t* __restrict__
 
 __global__ __launch_bounds__(TPB) void k_slab_fill(const uint32_t* __restrict__ parent, const uint8_t* __restrict__ flags,
                                                   const uint32_t* __restrict__ minord,
-                                                  const uint32_t* __restrict__ cellstart, uint32_t ncells,
+                                                  CellTab ct,
                                                   const uint32_t* __restrict__ blkscan, uint32_t* __restrict__ comps) {
-  const uint32_t nin = cellstart[ncells];
+  const uint32_t nin = *ct.nin;
   int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
   const bool root = p < nin && (flags[p] & F_EXPAND) && parent[p] == (uint32_t)p;
   __shared__ unsigned wc[TPB / 64];
@@ -1539,11 +1430,11 @@ __global__ __launch_bounds__(TPB) void k_slab_out(int64_t n, const uint32_t* __r
 // per root: index of its global cluster in the caller's table (binary search of the local seed)
 __global__ __launch_bounds__(TPB) void k_slab_rootk(const uint32_t* __restrict__ parent, const uint8_t* __restrict__ flags,
                                                    const uint32_t* __restrict__ minord,
-                                                   const uint32_t* __restrict__ cellstart, uint32_t ncells,
+                                                   CellTab ct,
                                                    const uint32_t* __restrict__ map_rep, const uint32_t* __restrict__ map_k,
                                                    uint32_t nmap, uint32_t* __restrict__ rootk,
                                                    unsigned long long* __restrict__ missing) {
-  const uint32_t nin = cellstart[ncells];
+  const uint32_t nin = *ct.nin;
   int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x;
   if (p >= nin) return;
   if ((flags[p] & F_EXPAND) && parent[p] == (uint32_t)p) {
@@ -1819,14 +1710,13 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   g.ncells = (uint32_t)ncells;
 
   // 3. workspace
-  VCP_TRY(vcp_ensure(ctx, ctx->b_cellcnt, (size_t)(ncells + 2) * 4));
+  // the cell table (grid_common.hpp: CellTab): 16 bytes per word of 32 cells, the full starts of the populous words, and
+  // two counters
+  const size_t ctw = vcp_ct_words(g.ncells), ctd = vcp_ct_dense_cap(n, g.ncells);
+  VCP_TRY(vcp_ensure(ctx, ctx->b_ctw, ctw * 16 + 64));
+  VCP_TRY(vcp_ensure(ctx, ctx->b_ctd, ctd * 128));
   VCP_TRY(vcp_ensure(ctx, ctx->b_cellof, (size_t)n * 4));
-  VCP_TRY(vcp_ensure(ctx, ctx->b_rank, (size_t)n * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_pos, (size_t)n * 4));
-  // cell order comes from the two-level partition (gridbuild.hip) unless the grid is too large for its one-level coarse
-  // split; only the sort-based build keeps a cell-ordered binary64 copy
-  const bool part = vcp_grid_partition_fits(n, g.ncells);
-  if (!part) VCP_TRY(vcp_ensure(ctx, ctx->b_sorted, (size_t)n * GD * 8));
   VCP_TRY(vcp_ensure(ctx, ctx->b_sorted32, (size_t)n * (GD == 2 ? 2 : 4) * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_sidx, (size_t)n * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_flags, (size_t)n));
@@ -1838,11 +1728,11 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   VCP_TRY(vcp_ensure(ctx, ctx->b_clseed, (size_t)n * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_labk, (size_t)n * 4));
   if (GROUPED) VCP_TRY(vcp_ensure(ctx, ctx->b_sgroup, (size_t)n * 4));
-  uint32_t* cellcnt = ctx->b_cellcnt.as<uint32_t>();
+  uint4* ctwords = ctx->b_ctw.as<uint4>();
+  uint32_t* ctcount = reinterpret_cast<uint32_t*>(ctx->b_ctw.as<char>() + ctw * 16);  // [0] populous words, [1] points in the grid
+  const CellTab ct{ctwords, ctx->b_ctd.as<uint32_t>(), ctcount + 1};
   uint32_t* cellof = ctx->b_cellof.as<uint32_t>();
-  uint32_t* rank = ctx->b_rank.as<uint32_t>();
   uint32_t* pos = ctx->b_pos.as<uint32_t>();
-  double* sorted = ctx->b_sorted.as<double>();
   float* sorted32 = ctx->b_sorted32.as<float>();
   static const bool screen_off = getenv("VCP_NO_SCREEN") != nullptr;
   // the screen compares values of the SCALED copies: threshold and extent in the same units
@@ -1862,15 +1752,14 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   unsigned long long* counters = reinterpret_cast<unsigned long long*>(d_bounds + 8);
   uint32_t* d_total = reinterpret_cast<uint32_t*>(counters + 2);
 
-  // 4. cell order.  Two-level partition that carries the coordinates (gridbuild.hip); grids too large for its
-  //    one-level coarse split keep the round-1 build: sort (cell id, index) pairs, cell starts from the sorted keys,
-  //    gather.  The partition's output pass needs no caller-order -> cell-order map (pos).
+  // 4. cell order: two-level partition that carries the binary32 coordinates and emits the cell table (gridbuild.hip);
+  //    its output pass needs no caller-order -> cell-order map (pos).  The binary64 coordinates stay in the caller's
+  //    array and are read by index where a screened pair needs the exact test.
   // flags before the core count: the build stores the callers' isClassed bits; without them the core count starts every
   // byte itself and nothing has to be there
   const bool flags_set = d_in_classed != nullptr;
-  ExactSrc xs{sorted, nullptr, GD};
-  const bool part_out = part && !GROUPED && !d_ord && !(ext && ext->slab) && n <= ((int64_t)1 << 27);
-  if (part) {
+  const bool part_out = !GROUPED && !d_ord && !(ext && ext->slab) && n <= ((int64_t)1 << 27);
+  {
     if (!flags_set && GROUPED) VCP_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)n, st));  // bytes of excluded points
     GridBuildArgs ga;
     ga.d_coords = d_coords;
@@ -1883,7 +1772,9 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
     ga.ghi = ghi;
     ga.d_ord = d_ord;
     ga.d_in_classed = d_in_classed;
-    ga.cellstart = cellcnt;
+    ga.ctwords = ctwords;
+    ga.ctdense = ctx->b_ctd.as<uint32_t>();
+    ga.ctcount = ctcount;
     ga.sidx = d_ord ? cellof : nullptr;  // the point's index where sord holds the caller's list position instead
     ga.sorted32 = sorted32;
     ga.sord = sord;
@@ -1891,35 +1782,8 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
     ga.flags = flags;
     ga.pos = part_out ? nullptr : pos;
     VCP_TRY(vcp_grid_build_partition(ctx, ga));
-    xs = ExactSrc{d_coords, d_ord ? cellof : sord, stride};  // staged calls: kept for vcp_slab_finish (SlabState.xs)
-  } else {
-    vcp_phase(ctx, "cell_key");
-    VCP_TRY(vcp_ensure(ctx, ctx->b_skey, (size_t)n * 4));
-    uint32_t* skey = ctx->b_skey.as<uint32_t>();
-    uint32_t* sidx = d_ord ? rank : sord;  // without a caller ord the sorted index is the list position itself
-    hipLaunchKernelGGL((k_cell_key<GD, GROUPED>), dim3(nb), dim3(TPB), 0, st, d_coords, n, stride, g, d_group, glo, ghi,
-                       cellof, d_ord ? sord : rank, pos);
-    uint32_t* vals_in = d_ord ? sord : rank;
-    vcp_phase(ctx, "cell_sort");
-    int bits = 1;
-    while (bits < 32 && (g.ncells >> bits) != 0) bits++;  // keys go up to ncells (excluded points)
-    size_t tb = 0;
-    VCP_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tb, cellof, skey, vals_in, sidx, (size_t)n, 0, bits, st));
-    VCP_TRY(vcp_ensure(ctx, ctx->b_sorttmp, tb));
-    VCP_HIP(ctx, rocprim::radix_sort_pairs(ctx->b_sorttmp.p, tb, cellof, skey, vals_in, sidx, (size_t)n, 0, bits, st));
-    vcp_phase(ctx, "cell_scan");
-    const int64_t ntiles = (ncells + 1 + CTILE - 1) / CTILE;  // the table has ncells + 1 entries
-    VCP_TRY(vcp_ensure(ctx, ctx->b_aux0, (size_t)(ntiles + 2) * 4));
-    uint32_t* tilestart = ctx->b_aux0.as<uint32_t>();
-    VCP_HIP(ctx, hipMemsetAsync(tilestart, 0, (size_t)(ntiles + 2) * 4, st));
-    hipLaunchKernelGGL(k_tile_marks, dim3(nb), dim3(TPB), 0, st, skey, n, tilestart);
-    VCP_TRY(vcp_exclusive_max_scan_u32(ctx, tilestart, tilestart, ntiles + 1, nullptr));
-    hipLaunchKernelGGL(k_cellstart_tiles, dim3((unsigned)ntiles), dim3(TPB), 0, st, skey, tilestart, g.ncells, cellcnt);
-    vcp_phase(ctx, "scatter");
-    if (!flags_set && GROUPED) VCP_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)n, st));  // bytes of excluded points
-    hipLaunchKernelGGL((k_gather<GD, GROUPED>), dim3(nb), dim3(TPB), 0, st, d_coords, stride, cellcnt, g.ncells, sidx,
-                       d_in_classed, d_group, d_ord, pos, sorted, sord, sgroup, flags, sorted32, g);
   }
+  const ExactSrc xs{d_coords, d_ord ? cellof : sord, stride};  // staged calls: kept for vcp_slab_finish (SlabState.xs)
 
   // 5. core flags + work lists (expanding points; non-core points that have a neighbour)
   vcp_phase(ctx, "core_count");
@@ -1947,15 +1811,15 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   }
   const size_t lds_nb = (size_t)no.NB * TPB * 4;
   if constexpr (GD == 2 && !GROUPED)
-    hipLaunchKernelGGL((k_core_lds<GD, METRIC>), dim3(nb), dim3(TPB), 0, st, xs, g, thr, min_pts, cellcnt, flags, parent,
+    hipLaunchKernelGGL((k_core_lds<GD, METRIC>), dim3(nb), dim3(TPB), 0, st, xs, g, thr, min_pts, ct, flags, parent,
                        minord, blkE, blkB, no, sorted32, sc, flags_set);
   else
-    hipLaunchKernelGGL((k_core<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 2 * lds_nb, st, xs, g, thr, min_pts, cellcnt,
+    hipLaunchKernelGGL((k_core<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 2 * lds_nb, st, xs, g, thr, min_pts, ct,
                        sgroup, flags, parent, minord, blkE, blkB, no, sorted32, sc, flags_set);
   // ONE scan over both count arrays (they are adjacent): the B half comes out offset by everything before it, which
   // its readers take off again (scan[0]); the two pad words between the halves are never written and cancel the same way
   VCP_TRY(vcp_exclusive_scan_u32(ctx, blkE, blkE, 2 * ((int64_t)nb + 2), nullptr));
-  hipLaunchKernelGGL(k_wl_fill, dim3(nb), dim3(TPB), 0, st, flags, cellcnt, g.ncells, blkE, blkB, wlE.list, wlB.list,
+  hipLaunchKernelGGL(k_wl_fill, dim3(nb), dim3(TPB), 0, st, flags, ct, blkE, blkB, wlE.list, wlB.list,
                      seedflag, nw, counters);
 
   // 6. components of the expanding points
@@ -1967,7 +1831,7 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
     hipLaunchKernelGGL(k_flatten0<true>, dim3(nbl), dim3(TPB), 0, st, parent, wlE, flags, no);
     hipLaunchKernelGGL(k_flatten0<false>, dim3(nbl), dim3(TPB), 0, st, parent, wlE, flags, no);
   } else if (GD == 2) {
-    hipLaunchKernelGGL((k_union_init<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, xs, g, thr, cellcnt, sgroup,
+    hipLaunchKernelGGL((k_union_init<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, xs, g, thr, ct, sgroup,
                        flags, parent, wlE, sorted32, sc);
     hipLaunchKernelGGL(k_flatten0<false>, dim3(nbl), dim3(TPB), 0, st, parent, wlE, flags, no);
   }
@@ -1975,23 +1839,23 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   if (dense) {
     VCP_TRY(vcp_ensure(ctx, ctx->b_aux0, ((size_t)nb * (TPB / 64) + 2) * 4));  // one word per wave of k_chunkroot
     uint32_t* chunkroot = ctx->b_aux0.as<uint32_t>();
-    hipLaunchKernelGGL(k_chunkroot, dim3(nb), dim3(TPB), 0, st, parent, cellcnt, g.ncells, chunkroot);
-    hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED, true, true>), dim3(nbl), dim3(TPB), 0, st, xs, g, thr, cellcnt, sgroup,
+    hipLaunchKernelGGL(k_chunkroot, dim3(nb), dim3(TPB), 0, st, parent, ct, chunkroot);
+    hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED, true, true>), dim3(nbl), dim3(TPB), 0, st, xs, g, thr, ct, sgroup,
                        parent, wlE, sorted32, sc, chunkroot);
   } else if (pre)
-    hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED, true>), dim3(nbl), dim3(TPB), 0, st, xs, g, thr, cellcnt, sgroup,
+    hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED, true>), dim3(nbl), dim3(TPB), 0, st, xs, g, thr, ct, sgroup,
                        parent, wlE, sorted32, sc);
   else
-    hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED, false>), dim3(nbl), dim3(TPB), 0, st, xs, g, thr, cellcnt, sgroup,
+    hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED, false>), dim3(nbl), dim3(TPB), 0, st, xs, g, thr, ct, sgroup,
                        parent, wlE, sorted32, sc);
   vcp_phase(ctx, "flatten_number");
   hipLaunchKernelGGL(k_flatten, dim3(nbl), dim3(TPB), 0, st, parent, sord, minord, wlE);
   if (!GROUPED && ext && ext->slab) {
     // staged call: hand the local components to the caller and keep the grid state for vcp_slab_finish
     vcp_phase(ctx, "slab_components");
-    hipLaunchKernelGGL(k_slab_count, dim3(nb), dim3(TPB), 0, st, parent, flags, cellcnt, g.ncells, blkE);
+    hipLaunchKernelGGL(k_slab_count, dim3(nb), dim3(TPB), 0, st, parent, flags, ct, blkE);
     VCP_TRY(vcp_exclusive_scan_u32(ctx, blkE, blkE, (int64_t)nb + 1, nullptr));
-    hipLaunchKernelGGL(k_slab_fill, dim3(nb), dim3(TPB), 0, st, parent, flags, minord, cellcnt, g.ncells, blkE, clseed);
+    hipLaunchKernelGGL(k_slab_fill, dim3(nb), dim3(TPB), 0, st, parent, flags, minord, ct, blkE, clseed);
     hipLaunchKernelGGL(k_slab_out, dim3(nb), dim3(TPB), 0, st, n, pos, flags, parent, minord, ext->d_slab_rep, d_is_core);
     VCP_HIP(ctx, hipGetLastError());
     uint32_t* hn = reinterpret_cast<uint32_t*>(ctx->pinned) + 64;
@@ -2021,12 +1885,12 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   // 7. border rule, then outputs in caller order
   vcp_phase(ctx, "border");
   if (GROUPED) VCP_HIP(ctx, hipMemsetAsync(ext->d_group_twice, 0, (size_t)G * 4, st));
-  hipLaunchKernelGGL(k_labk_rest, dim3(nb), dim3(TPB), 0, st, flags, parent, rootk, labk, cellcnt, g.ncells);
+  hipLaunchKernelGGL(k_labk_rest, dim3(nb), dim3(TPB), 0, st, flags, parent, rootk, labk, ct);
   if (no.NB > 0)
     hipLaunchKernelGGL(k_border_list<GROUPED>, dim3(nbl), dim3(TPB), 0, st, sgroup, flags, sord, rootk, clseed, labk, counters,
                        GROUPED ? ext->d_group_twice : nullptr, no, wlB);
   else
-    hipLaunchKernelGGL((k_border<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, xs, g, thr, cellcnt, sgroup, flags,
+    hipLaunchKernelGGL((k_border<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, xs, g, thr, ct, sgroup, flags,
                        parent, sord, rootk, clseed, labk, counters, GROUPED ? ext->d_group_twice : nullptr, wlB, 0u, NONE,
                        sorted32, sc);
   if (part_out) {
@@ -2082,7 +1946,9 @@ int run_slab_finish(vcp_ctx* ctx, const SlabState& ss, const uint32_t* d_map_rep
   const int64_t n = ss.n;
   const unsigned nb = ss.nb;
   const GridP g = ss.g;
-  uint32_t* cellcnt = ctx->b_cellcnt.as<uint32_t>();
+  const size_t ctw = vcp_ct_words(g.ncells);
+  const CellTab ct{ctx->b_ctw.as<uint4>(), ctx->b_ctd.as<uint32_t>(),
+                   reinterpret_cast<uint32_t*>(ctx->b_ctw.as<char>() + ctw * 16) + 1};
   uint32_t* pos = ctx->b_pos.as<uint32_t>();
   uint32_t* sord = ctx->b_sidx.as<uint32_t>();
   uint8_t* flags = ctx->b_flags.as<uint8_t>();
@@ -2103,12 +1969,12 @@ int run_slab_finish(vcp_ctx* ctx, const SlabState& ss, const uint32_t* d_map_rep
   unsigned long long* counters = reinterpret_cast<unsigned long long*>(ctx->b_misc.as<double>() + (size_t)rb * 8 + 8);
   vcp_phase(ctx, "slab_roots");
   VCP_HIP(ctx, hipMemsetAsync(counters, 0, 68 * sizeof(unsigned long long), st));
-  hipLaunchKernelGGL(k_slab_rootk, dim3(nb), dim3(TPB), 0, st, parent, flags, minord, cellcnt, g.ncells, d_map_rep, d_map_k,
+  hipLaunchKernelGGL(k_slab_rootk, dim3(nb), dim3(TPB), 0, st, parent, flags, minord, ct, d_map_rep, d_map_k,
                      (uint32_t)ss.n_comp, rootk, counters);
   vcp_phase(ctx, "border");
-  hipLaunchKernelGGL(k_labk_rest, dim3(nb), dim3(TPB), 0, st, flags, parent, rootk, labk, cellcnt, g.ncells);
+  hipLaunchKernelGGL(k_labk_rest, dim3(nb), dim3(TPB), 0, st, flags, parent, rootk, labk, ct);
   hipLaunchKernelGGL((k_border<GD, METRIC, false>), dim3(nbl), dim3(TPB), 0, st, ss.xs, g, ss.thr,
-                     cellcnt, nullptr, flags, parent, sord, rootk, clseed, labk, counters, nullptr, wlB, own_lo, own_span,
+                     ct, nullptr, flags, parent, sord, rootk, clseed, labk, counters, nullptr, wlB, own_lo, own_span,
                      ctx->b_sorted32.as<float>(), ss.sc);
   vcp_phase(ctx, "output");
   hipLaunchKernelGGL(k_slab_output, dim3(nb), dim3(TPB), 0, st, n, pos, labk, d_tab_gid, d_labels, d_is_classed);

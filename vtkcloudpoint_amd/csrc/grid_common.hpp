@@ -102,6 +102,35 @@ __device__ __forceinline__ uint32_t cell_of32(const float* qf, const GridP& g, i
   return cell_id<GD>(g, cc[0], cc[1], cc[2]);
 }
 
+// ---- the cell table ---------------------------------------------------------------------------------------------
+// start(c) = cell-ordered position of the first point whose cell id is >= c, for 0 <= c <= ncells.  A dense array of
+// starts costs 4 bytes per CELL -- on the sparse grids of this path (10-30 cells per point: 40-120 bytes per point) it
+// was the largest stream of the build and of the region query.  The table is kept per WORD of 32 consecutive cells
+// instead, 16 bytes each (0.5 byte per cell):
+//   lo, hi   two bit planes: the cell's population, saturated at 3 (lo & hi = "3 or more")
+//   wpos     start of the word's first cell
+//   slot     where a word with a populous cell keeps its 32 starts in full (`dense`, 128 bytes), else unused
+// start(c) = wpos + popcount(lo below c) + 2 popcount(hi below c) while no cell below c in the word is populous -- ONE
+// 16-byte load and no dependent one; otherwise dense[32 slot + (c & 31)].  Populous words are the inside of blobs: few
+// (every one holds >= 3 points), hot in cache, and 4 bytes per cell is what they would have cost anyway.
+struct CellTab {
+  const uint4* words;      // [(ncells + 32) / 32]
+  const uint32_t* dense;   // [32 * number of populous words]
+  const uint32_t* nin;     // number of points in the grid (= start(ncells))
+};
+
+__device__ __forceinline__ uint32_t ct_start(const CellTab& t, uint32_t cell) {
+  const uint4 w = t.words[cell >> 5];
+  const uint32_t i = cell & 31u, below = (1u << i) - 1u;
+  if ((w.x & w.y & below) == 0u) return w.z + (uint32_t)__popc(w.x & below) + 2u * (uint32_t)__popc(w.y & below);
+  return t.dense[(size_t)w.w * 32u + i];
+}
+// two bounds of one word-local range (rows: x0 .. x1 + 1 are at most 3 cells apart and usually share a word)
+__device__ __forceinline__ void ct_range(const CellTab& t, uint32_t c0, uint32_t c1, uint32_t& s, uint32_t& e) {
+  s = ct_start(t, c0);
+  e = ct_start(t, c1);
+}
+
 // ---- binary32 screening of the distance predicate ----------------------------------------------------------
 // The search kernels decide `d(p, j) <= eps` on binary32 copies of the coordinates, taken relative to the grid origin,
 // wherever that decision is provably the binary64 one: value <= lo -> inside, value > hi -> outside, anything else
@@ -167,7 +196,9 @@ struct GridBuildArgs {
   const uint32_t* d_ord = nullptr;          // list position of point i (NULL = i)
   const uint8_t* d_in_classed = nullptr;    // NULL = flags are zero-filled by the caller
   // outputs (cell order unless noted)
-  uint32_t* cellstart = nullptr;  // [ncells + 1]
+  uint4* ctwords = nullptr;       // [(ncells + 32) / 32] the cell table (CellTab)
+  uint32_t* ctdense = nullptr;    // [32 * min(words, n / 3 + 1)] full starts of the populous words
+  uint32_t* ctcount = nullptr;    // [2]: [0] populous words handed out so far (zero on entry), [1] <- points in the grid
   float* sorted32 = nullptr;      // [nin * (gd == 2 ? 2 : 4)] binary32 coordinates relative to g.mn (binning, screening)
   uint32_t* sord = nullptr;       // [nin] list position (d_ord of the point's index)
   uint32_t* sidx = nullptr;       // [nin] the point's index in d_coords; NULL = not wanted (it is sord without d_ord)
@@ -175,8 +206,12 @@ struct GridBuildArgs {
   uint8_t* flags = nullptr;       // [nin], written only with d_in_classed
   uint32_t* pos = nullptr;        // [n] caller order, NONE for left-out points; NULL = not wanted
 };
-// false when the grid is too large for the one-level coarse partition (the caller keeps the sort-based build)
-bool vcp_grid_partition_fits(int64_t n, uint32_t ncells);
+// words of the cell table of a grid of ncells cells, and populous words a cloud of n points can have at most
+__host__ __device__ static inline size_t vcp_ct_words(uint32_t ncells) { return ((size_t)ncells + 32) / 32; }
+static inline size_t vcp_ct_dense_cap(int64_t n, uint32_t ncells) {
+  const size_t w = vcp_ct_words(ncells), byn = (size_t)n / 3 + 1;
+  return w < byn ? w : byn;
+}
 int vcp_grid_build_partition(vcp_ctx* ctx, const GridBuildArgs& a);
 
 // Cell order -> caller order the same way (no per-point random gather): (list position, label word) pairs are

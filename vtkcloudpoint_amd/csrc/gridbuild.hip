@@ -13,10 +13,13 @@
 //   k_part_scatter  per chunk: the scanned counts become per-bucket cursors in LDS; one returning LDS atomic per point
 //                   gives the slot of its record in the bucket-major record array -- each chunk owns a contiguous run
 //                   per bucket, so partial lines are completed in the writing XCD's L2
+//   (k_part_split)  grids of more than 8192 buckets (very sparse: C5's 1.4 G cells): the coarse passes run on
+//                   super-buckets of up to 32 buckets and this pass splits each into its buckets, cursors in LDS
 //   k_part_fine     one workgroup per bucket: count the bucket's records per cell in LDS, scan, store the bucket's
-//                   slice of the cell table coalesced (written exactly once, never zero-filled), then assemble the
-//                   bucket in LDS in its final order and store it as full lines: binary32 coordinates, list position,
-//                   and the optional per-point extras.
+//                   slice of the CELL TABLE (grid_common.hpp: CellTab -- two bit planes + a start per word of 32 cells,
+//                   full starts only for words with a populous cell; written exactly once, never zero-filled), then
+//                   assemble the bucket in LDS in its final order and store it as full lines: binary32 coordinates,
+//                   list position, and the optional per-point extras.
 //
 // and back (vcp_grid_output_partition): (list position, label word) pairs partitioned by windows of 2^OWSH list
 // positions, every window then written by workgroups that share an XCD (b and b+8 share an L2).
@@ -84,6 +87,8 @@ __device__ __forceinline__ uint32_t point_cell(const double* __restrict__ c, int
 struct PartGeom {
   uint32_t csh;     // log2(cells per bucket)
   uint32_t B;       // buckets
+  uint32_t a;       // log2(buckets per super-bucket): 0 unless B > MAXB
+  uint32_t NS;      // super-buckets = what the coarse passes split into (= B when a == 0)
   uint32_t chunk;   // points per chunk (a multiple of PT)
   uint32_t nchunk;
 };
@@ -100,6 +105,9 @@ inline PartGeom part_geom(int64_t n, uint32_t ncells) {
   PartGeom p;                                                           // than workgroups per CU (part_bench)
   p.csh = (uint32_t)csh;
   p.B = (uint32_t)((((uint64_t)ncells + 1) + ((1ull << p.csh) - 1)) >> p.csh);  // the table has ncells + 1 entries
+  p.a = 0;
+  while (((p.B + (1u << p.a) - 1u) >> p.a) > MAXB) p.a++;  // ncells < 2^31, csh >= 10: a <= 8; with csh 14 a <= 4
+  p.NS = (p.B + (1u << p.a) - 1u) >> p.a;
   int64_t chunk = (n + target - 1) / target;
   if (chunk < PCH_MIN) chunk = PCH_MIN;
   chunk = (chunk + PT - 1) / PT * PT;
@@ -112,9 +120,13 @@ template <int GD, bool GROUPED>
 __global__ __launch_bounds__(PT) void k_part_hist(const double* __restrict__ c, int64_t n, int stride, GridP g,
                                                  const int32_t* __restrict__ group, int glo, int ghi, uint32_t csh,
                                                  uint32_t B, uint32_t chunk, uint32_t nchunk,
-                                                 uint32_t* __restrict__ counts, uint32_t* __restrict__ qcount) {
+                                                 uint32_t* __restrict__ counts, uint32_t* __restrict__ qcount,
+                                                 uint32_t* __restrict__ ctcount) {
   extern __shared__ uint32_t h[];
-  if (blockIdx.x == 0 && threadIdx.x == 0) *qcount = 0u;  // the fine pass's queue of windows (k_part_fine_windows)
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *qcount = 0u;      // the fine pass's queue of windows (k_part_fine_windows)
+    ctcount[0] = 0u;   // populous words of the cell table handed out (k_part_fine)
+  }
   for (uint32_t k = threadIdx.x; k < B; k += PT) h[k] = 0;
   __syncthreads();
   const int64_t first = (int64_t)blockIdx.x * chunk;
@@ -170,7 +182,7 @@ __device__ __forceinline__ uint32_t padded(uint32_t i) { return i + (i >> 5); }
 // of a cluster) keeps, from the counting pass, each record's RANK inside its cell (rk, 4 B per record), so that its
 // final position start[cell] + rank is known without a cursor, and walks its records once per window of WCAP
 // positions (the records of a bucket stay L2-resident).
-template <int GD, bool GROUPED>
+template <int GD, bool GROUPED, int NT = FT>
 __device__ __forceinline__ void fine_flush(uint32_t s0, uint32_t m, const float* s32, const uint32_t* sidx,
                                            const uint32_t* __restrict__ ord, const uint8_t* __restrict__ in_classed,
                                            const int32_t* __restrict__ group, float* __restrict__ sorted32,
@@ -180,13 +192,13 @@ __device__ __forceinline__ void fine_flush(uint32_t s0, uint32_t m, const float*
   if (GD == 2) {
     const float2* src = reinterpret_cast<const float2*>(s32);
     float2* dst = reinterpret_cast<float2*>(sorted32) + s0;
-    for (uint32_t k = threadIdx.x; k < m; k += FT) dst[k] = src[k];
+    for (uint32_t k = threadIdx.x; k < m; k += NT) dst[k] = src[k];
   } else {
     const float4* src = reinterpret_cast<const float4*>(s32);
     float4* dst = reinterpret_cast<float4*>(sorted32) + s0;
-    for (uint32_t k = threadIdx.x; k < m; k += FT) dst[k] = src[k];
+    for (uint32_t k = threadIdx.x; k < m; k += NT) dst[k] = src[k];
   }
-  for (uint32_t k = threadIdx.x; k < m; k += FT) {
+  for (uint32_t k = threadIdx.x; k < m; k += NT) {
     const uint32_t i = sidx[k], p = s0 + k;
     sord[p] = ord ? ord[i] : i;
     if (sidx_out) sidx_out[p] = i;
@@ -204,19 +216,273 @@ __device__ __forceinline__ void stage_put(float* s32, uint32_t* sidx, uint32_t p
   sidx[p] = idx;
 }
 
+// first / one-past-last record of bucket b: from the scanned (bucket, chunk) counts of the coarse passes (stride =
+// chunks) or, after k_part_split, from the array of bucket starts (stride 1); the last bucket ends at *total
+__device__ __forceinline__ void bucket_range(const uint32_t* __restrict__ bstart, uint32_t bstride, const uint32_t* __restrict__ total,
+                                             uint32_t b, uint32_t B, uint32_t& s, uint32_t& e) {
+  s = bstart[(size_t)b * bstride];
+  e = (b + 1 < B) ? bstart[(size_t)(b + 1) * bstride] : *total;
+}
+
+// Grids of more than MAXB buckets: the coarse passes ran on super-buckets of 2^a consecutive buckets.  One workgroup per
+// super-bucket counts its records per bucket in LDS (at most 32 counters), publishes the bucket starts and moves the
+// records into bucket order (rec -> rec2; the super-bucket's ~10^4 records stay in the writing XCD's L2).
+template <int GD>
+__global__ __launch_bounds__(FT) void k_part_split(const Rec* __restrict__ rec, Rec* __restrict__ rec2,
+                                                  const uint32_t* __restrict__ base, const uint32_t* __restrict__ total,
+                                                  uint32_t nchunk, uint32_t NS, uint32_t a, uint32_t csh, uint32_t B, GridP g,
+                                                  uint32_t* __restrict__ bstart) {
+  __shared__ uint32_t h[32];
+  const uint32_t S = blockIdx.x;
+  uint32_t s, e;
+  bucket_range(base, nchunk, total, S, NS, s, e);
+  const uint32_t subm = (1u << a) - 1u;
+  if (threadIdx.x < 32) h[threadIdx.x] = 0u;
+  __syncthreads();
+  for (uint32_t j = s + threadIdx.x; j < e; j += FT) {
+    uint32_t i;
+    atomicAdd(&h[(rec_cell<GD>(rec[j], g, i) >> csh) & subm], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const uint32_t v = h[threadIdx.x];
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+      const uint32_t t = __shfl_up(inc, d, 64);
+      if ((int)threadIdx.x >= d) inc += t;
+    }
+    const uint32_t first = s + inc - v;
+    h[threadIdx.x] = first;
+    const uint32_t bk = (S << a) + threadIdx.x;
+    if (threadIdx.x <= subm && bk <= B) bstart[bk] = first;  // bstart[B] = *total: behind the last bucket nothing follows
+  }
+  __syncthreads();
+  for (uint32_t j = s + threadIdx.x; j < e; j += FT) {
+    const Rec r = rec[j];
+    uint32_t i;
+    rec2[atomicAdd(&h[(rec_cell<GD>(r, g, i) >> csh) & subm], 1u)] = r;
+  }
+}
+
+// ---- fine pass, small buckets -------------------------------------------------------------------------------
+// A bucket of up to SCAP records is worked at the granularity of the cell table's WORDS (512 per bucket) instead of its
+// 2^14 cells: the dense per-cell counters of k_part_fine cost the same ~11 us per bucket however few records it holds
+// (zero, scan and read back 16 k counters at one workgroup per CU), which made the fine pass the largest phase on sparse
+// grids (noise pass of the block pipeline: 6 k buckets of ~800 records; C5: 85 k buckets of ~600).  Here: records are
+// counted and grouped per word; a word whose cells all hold at most two records (the sparse background) gets its bit
+// planes from a short sequential walk by one thread and its records their final place from the planes; a POPULOUS word
+// (some cell with three or more: the inside of a blob) gets 32 cell counters in LDS, worked by a half-wave.  Work is
+// O(records + words), 50 KB of LDS: three workgroups per CU.  Buckets with more than SCAP records or more than SPOP
+// populous words are left to k_part_fine (bstate[b] = 1).
+constexpr int FS = 512;            // threads
+constexpr uint32_t scap(int gd) { return gd == 2 ? 2048u : 1536u; }  // records: 42 / 50 KB of LDS, three workgroups per CU
+// (4096 records and 256 populous words -- 75 KB, two workgroups per CU -- was measured: C4 fine pass 0.20 ms either way,
+// C5 1.65 against 1.22 ms, noise pass of the block pipeline 0.160 against 0.131 ms)
+constexpr uint32_t SPOP = 128;     // populous words
+
+template <int GD, bool GROUPED>
+__global__ __launch_bounds__(FS) void k_part_fine_small(const Rec* __restrict__ rec, const uint32_t* __restrict__ bstart,
+                                                       uint32_t bstride, const uint32_t* __restrict__ total, uint32_t B,
+                                                       uint32_t csh, GridP g, const uint32_t* __restrict__ ord,
+                                                       const uint8_t* __restrict__ in_classed, const int32_t* __restrict__ group,
+                                                       uint4* __restrict__ ctwords, uint32_t* __restrict__ ctdense,
+                                                       uint32_t* __restrict__ ctcount, uint8_t* __restrict__ bstate,
+                                                       float* __restrict__ sorted32, uint32_t* __restrict__ sord,
+                                                       uint32_t* __restrict__ sidx_out, int32_t* __restrict__ sgroup,
+                                                       uint8_t* __restrict__ flags, uint32_t* __restrict__ pos) {
+  constexpr uint32_t FPR = GD == 2 ? 2 : 4;
+  constexpr uint32_t SCAP = scap(GD);
+  constexpr int SRPT = SCAP / FS;             // records per thread, kept in registers between the phases
+  __shared__ uint32_t ws[512 + 2];            // records per word, then first position of each word (+ the bucket's end)
+  __shared__ uint32_t wlo[512], whi[512];     // the words' bit planes
+  __shared__ uint16_t wpi[512];               // populous words: index among the bucket's populous words
+  __shared__ uint8_t sci[SCAP];               // cell inside the word of each record, word-grouped order
+  __shared__ __attribute__((aligned(16))) uint16_t st32[SPOP][32];         // populous words: cell counters -> starts -> cursors, relative to the bucket
+  __shared__ __attribute__((aligned(16))) float s32[SCAP * FPR];  // final order: coordinates ...
+  __shared__ uint32_t sidx[SCAP];                                 // ... and the points' indices
+  __shared__ uint32_t wsum[FS / 64];
+  __shared__ uint32_t s_np, s_dbase;
+  const uint32_t b = blockIdx.x;
+  uint32_t s, e;
+  bucket_range(bstart, bstride, total, b, B, s, e);
+  const uint32_t m = e - s;
+  if (b + 1 == B && threadIdx.x == 0) ctcount[1] = *total;  // points in the grid (CellTab::nin)
+  if (m > SCAP) {                                            // k_part_fine's
+    if (threadIdx.x == 0) bstate[b] = 1;
+    return;
+  }
+  const uint32_t CPB = 1u << csh, NW = CPB >> 5, c0 = b << csh;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (uint32_t k = threadIdx.x; k < NW + 1; k += FS) ws[k] = 0u;
+  __syncthreads();
+  // A. count per word; the record stays in registers
+  Rec r[SRPT];
+  uint32_t idx[SRPT], lw[SRPT], ci[SRPT], rnk[SRPT];
+#pragma unroll
+  for (int k = 0; k < SRPT; k++) {
+    const uint32_t j = s + (uint32_t)k * FS + threadIdx.x;
+    lw[k] = NONE;
+    if (j < e) {
+      r[k] = rec[j];
+      const uint32_t c = rec_cell<GD>(r[k], g, idx[k]) - c0;
+      lw[k] = c >> 5;
+      ci[k] = c & 31u;
+      rnk[k] = atomicAdd(&ws[lw[k]], 1u);
+    }
+  }
+  __syncthreads();
+  // B. word starts: exclusive scan of the NW (<= 512 = FS) counts
+  {
+    const uint32_t v = threadIdx.x < NW ? ws[threadIdx.x] : 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t t = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += t;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t pre = inc - v;
+    for (int k = 0; k < w; k++) pre += wsum[k];
+    if (threadIdx.x < NW) ws[threadIdx.x] = s + pre;
+    if (threadIdx.x == 0) ws[NW] = e;
+  }
+  __syncthreads();
+  // C. the cells of a word's records, side by side
+#pragma unroll
+  for (int k = 0; k < SRPT; k++)
+    if (lw[k] != NONE) sci[ws[lw[k]] - s + rnk[k]] = (uint8_t)ci[k];
+  __syncthreads();
+  // D. bit planes of the words that can have them from a short walk (more than 64 records: some cell holds three)
+  bool popl = false;
+  uint32_t lo = 0u, hi = 0u;
+  if (threadIdx.x < NW) {
+    const uint32_t a = ws[threadIdx.x] - s, k = ws[threadIdx.x + 1] - s - a;
+    if (k > 64u) {
+      popl = true;
+    } else {
+      for (uint32_t i = 0; i < k; i++) {
+        const uint32_t bit = 1u << sci[a + i];
+        if (lo & hi & bit) continue;  // saturated at three
+        if (lo & bit) hi ^= bit;      // 1 -> 2, (2 -> 3 below)
+        lo ^= bit;
+      }
+      popl = (lo & hi) != 0u;
+    }
+  }
+  {
+    const unsigned long long dm = __ballot(popl);
+    if (lane == 0) wsum[w] = (uint32_t)__popcll(dm);
+    __syncthreads();
+    uint32_t before = (uint32_t)__popcll(dm & ((1ull << lane) - 1ull)), tot = 0;
+    for (int k = 0; k < FS / 64; k++) {
+      if (k < w) before += wsum[k];
+      tot += wsum[k];
+    }
+    if (threadIdx.x == 0) s_np = tot;
+    if (threadIdx.x < NW) wpi[threadIdx.x] = popl ? (uint16_t)before : (uint16_t)0xFFFFu;
+  }
+  __syncthreads();
+  const uint32_t np = s_np;
+  if (np > SPOP) {  // a bucket in the thick of a blob: the dense pass does it (uniform over the workgroup)
+    if (threadIdx.x == 0) bstate[b] = 1;
+    return;
+  }
+  if (threadIdx.x == 0) {
+    bstate[b] = 0;
+    s_dbase = np ? atomicAdd(&ctcount[0], np) : 0u;
+  }
+  for (uint32_t k = threadIdx.x; k < np * 16u; k += FS) reinterpret_cast<uint32_t*>(&st32[0][0])[k] = 0u;
+  if (threadIdx.x < NW && !popl) {
+    wlo[threadIdx.x] = lo;
+    whi[threadIdx.x] = hi;
+  }
+  __syncthreads();
+  // E. populous words: count per cell ...
+#pragma unroll
+  for (int k = 0; k < SRPT; k++)
+    if (lw[k] != NONE && wpi[lw[k]] != 0xFFFFu) {  // 16-bit counters: an atomic add on the containing word
+      uint16_t* c = &st32[wpi[lw[k]]][ci[k]];
+      atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(c) & ~(uintptr_t)3), ((uintptr_t)c & 2) ? 0x10000u : 1u);
+    }
+  __syncthreads();
+  // ... starts, bit planes and the full slice of the table, one half-wave per populous word
+  {
+    const uint32_t hw = threadIdx.x >> 5, li = threadIdx.x & 31u;
+    for (uint32_t wd = hw; wd < NW; wd += FS / 32) {  // (uniform per half-wave)
+      const uint32_t pi = wpi[wd];
+      if (pi == 0xFFFFu) continue;
+      const uint32_t c = st32[pi][li];
+      uint32_t inc = c;  // (a cell of a bucket of <= 4096 records holds < 65536)
+#pragma unroll
+      for (int d = 1; d < 32; d <<= 1) {
+        const uint32_t t = __shfl_up(inc, d, 32);
+        if ((int)li >= d) inc += t;
+      }
+      const uint32_t first = ws[wd] + inc - c;
+      st32[pi][li] = (uint16_t)(first - s);  // cursor
+      ctdense[(size_t)(s_dbase + pi) * 32u + li] = first;
+      const uint32_t cs = min(c, 3u);
+      // planes by a 32-lane ballot: the half-wave's bits of the wave-wide mask
+      const unsigned long long blo = __ballot(cs & 1u), bhi = __ballot(cs >> 1);
+      const int sh = (threadIdx.x & 32) ? 32 : 0;
+      if (li == 0) {
+        wlo[wd] = (uint32_t)(blo >> sh);
+        whi[wd] = (uint32_t)(bhi >> sh);
+      }
+    }
+  }
+  __syncthreads();
+  // F. every record's final place
+#pragma unroll
+  for (int k = 0; k < SRPT; k++) {
+    if (lw[k] == NONE) continue;
+    const uint32_t pi = wpi[lw[k]];
+    uint32_t p;
+    if (pi != 0xFFFFu) {
+      uint16_t* c = &st32[pi][ci[k]];
+      const bool up = ((uintptr_t)c & 2) != 0;
+      const uint32_t old = atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(c) & ~(uintptr_t)3), up ? 0x10000u : 1u);
+      p = up ? old >> 16 : old & 0xFFFFu;
+    } else {
+      const uint32_t l = wlo[lw[k]], h = whi[lw[k]], below = (1u << ci[k]) - 1u;
+      const uint32_t a = ws[lw[k]] - s;
+      p = a + (uint32_t)__popc(l & below) + 2u * (uint32_t)__popc(h & below);
+      if ((h >> ci[k]) & 1u)  // two records in this cell: the one met first in the word goes first
+        for (uint32_t i = 0; i < rnk[k]; i++) p += sci[a + i] == (uint8_t)ci[k] ? 1u : 0u;
+    }
+    stage_put<GD>(s32, sidx, p, r[k], idx[k]);
+  }
+  // the bucket's words of the table
+  if (threadIdx.x < NW) {
+    const size_t W = (size_t)(c0 >> 5) + threadIdx.x;
+    const uint32_t pi = wpi[threadIdx.x];
+    if (W < vcp_ct_words(g.ncells))
+      ctwords[W] = make_uint4(wlo[threadIdx.x], whi[threadIdx.x], ws[threadIdx.x], pi != 0xFFFFu ? s_dbase + pi : NONE);
+  }
+  __syncthreads();
+  fine_flush<GD, GROUPED, FS>(s, m, s32, sidx, ord, in_classed, group, sorted32, sord, sidx_out, sgroup, flags, pos);
+}
+
 template <int GD, bool GROUPED>
 __global__ __launch_bounds__(FT) void k_part_fine(const Rec* __restrict__ rec, uint32_t* __restrict__ rk,
-                                                 const uint32_t* __restrict__ base, const uint32_t* __restrict__ total,
-                                                 uint32_t nchunk, uint32_t B, uint32_t csh, GridP g,
+                                                 const uint32_t* __restrict__ bstart, uint32_t bstride,
+                                                 const uint32_t* __restrict__ total, uint32_t B, uint32_t csh, GridP g,
                                                  const uint32_t* __restrict__ ord, const uint8_t* __restrict__ in_classed,
-                                                 const int32_t* __restrict__ group, uint32_t* __restrict__ cellstart,
+                                                 const int32_t* __restrict__ group, uint4* __restrict__ ctwords,
+                                                 uint32_t* __restrict__ ctdense, uint32_t* __restrict__ ctcount,
                                                  float* __restrict__ sorted32, uint32_t* __restrict__ sord,
                                                  uint32_t* __restrict__ sidx_out, int32_t* __restrict__ sgroup,
                                                  uint8_t* __restrict__ flags, uint32_t* __restrict__ pos,
-                                                 uint2* __restrict__ queue, uint32_t* __restrict__ qcount) {
+                                                 uint2* __restrict__ queue, uint32_t* __restrict__ qcount,
+                                                 const uint8_t* __restrict__ bstate) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   __shared__ uint32_t wsum[FT / 64];
+  __shared__ uint32_t w_lo[512], w_hi[512], w_slot[512];  // the bucket's words of the cell table (2^14 cells at most)
+  __shared__ uint32_t s_dbase;
   const uint32_t b = blockIdx.x;
+  if (bstate[b] == 0) return;  // done by k_part_fine_small
   constexpr uint32_t WCAP = wcap(GD);
   constexpr uint32_t FPR = GD == 2 ? 2 : 4;  // staged floats per record
   const uint32_t CPB = 1u << csh;
@@ -224,8 +490,8 @@ __global__ __launch_bounds__(FT) void k_part_fine(const Rec* __restrict__ rec, u
   float* s32 = reinterpret_cast<float*>(lds + (((size_t)padded(CPB) + 4) & ~3ull) * 4);  // [WCAP * FPR]
   uint32_t* sidx = reinterpret_cast<uint32_t*>(s32 + (size_t)WCAP * FPR);            // [WCAP]
   const uint32_t c0 = b << csh;
-  const uint32_t s = base[(size_t)b * nchunk];
-  const uint32_t e = (b + 1 < B) ? base[(size_t)(b + 1) * nchunk] : *total;
+  uint32_t s, e;
+  bucket_range(bstart, bstride, total, b, B, s, e);
   const uint32_t m = e - s;
   const bool big = m > WCAP;
   for (uint32_t k = threadIdx.x; k < padded(CPB); k += FT) cnt[k] = 0;
@@ -253,15 +519,61 @@ __global__ __launch_bounds__(FT) void k_part_fine(const Rec* __restrict__ rec, u
   __syncthreads();
   uint32_t pre = s + inc - loc;
   for (int k = 0; k < w; k++) pre += wsum[k];
-  for (uint32_t k = 0; k < PER; k++) {
-    const uint32_t v = cnt[padded(first + k)];
-    cnt[padded(first + k)] = pre;
-    pre += v;
+  // second pass of the scan; the thread's run of PER cells is part of ONE word of the cell table (PER <= 16): its bits of
+  // the two population planes are built on the way and OR-ed together over the 32 / PER threads that share the word
+  const uint32_t NW = CPB >> 5;
+  uint32_t plo = 0u, phi = 0u;
+  const uint32_t wstart = pre;  // start of the thread's first cell
+  {
+    const uint32_t bit0 = first & 31u;
+    for (uint32_t k = 0; k < PER; k++) {
+      const uint32_t v = cnt[padded(first + k)];
+      cnt[padded(first + k)] = pre;
+      pre += v;
+      const uint32_t c = min(v, 3u);
+      plo |= (c & 1u) << (bit0 + k);
+      phi |= (c >> 1) << (bit0 + k);
+    }
+    for (uint32_t d = 1; d < 32u / PER; d <<= 1) {
+      plo |= (uint32_t)__shfl_xor((int)plo, (int)d, 64);
+      phi |= (uint32_t)__shfl_xor((int)phi, (int)d, 64);
+    }
+    if ((first & 31u) == 0u) {  // the word's first thread
+      w_lo[first >> 5] = plo;
+      w_hi[first >> 5] = phi;
+      w_slot[first >> 5] = wstart;  // (its slot is settled below; until then the start of the word's first cell)
+    }
   }
   __syncthreads();
-  // the bucket's slice of the cell table, coalesced; entries up to and including index ncells exist
-  for (uint32_t k = threadIdx.x; k < CPB; k += FT)
-    if (c0 + k <= g.ncells) cellstart[c0 + k] = cnt[padded(k)];
+  {
+    // populous words (some cell with 3 or more points) keep their 32 starts in full: they are numbered inside the
+    // workgroup and take consecutive slots behind ONE atomic per bucket (a single hot word serialises at ~11 ns)
+    const bool popl = threadIdx.x < NW && (w_lo[threadIdx.x] & w_hi[threadIdx.x]) != 0u;
+    const unsigned long long dm = __ballot(popl);
+    if (lane == 0) wsum[w] = (uint32_t)__popcll(dm);
+    __syncthreads();
+    uint32_t before = (uint32_t)__popcll(dm & ((1ull << lane) - 1ull)), tot = 0;
+    for (int k = 0; k < FT / 64; k++) {
+      if (k < w) before += wsum[k];
+      tot += wsum[k];
+    }
+    if (threadIdx.x == 0) s_dbase = tot ? atomicAdd(&ctcount[0], tot) : 0u;
+    __syncthreads();
+    if (threadIdx.x < NW) {
+      const uint32_t slot = popl ? s_dbase + before : NONE;
+      const uint32_t wpos = w_slot[threadIdx.x];
+      w_slot[threadIdx.x] = slot;
+      const size_t W = (size_t)(c0 >> 5) + threadIdx.x;
+      if (W < vcp_ct_words(g.ncells))
+        ctwords[W] = make_uint4(w_lo[threadIdx.x], w_hi[threadIdx.x], wpos, slot);
+    }
+    __syncthreads();
+    const uint32_t hw = threadIdx.x >> 5, li = threadIdx.x & 31u;  // half-waves: one populous word (128 bytes) each
+    for (uint32_t j = hw; j < NW; j += FT / 32) {
+      const uint32_t slot = w_slot[j];
+      if (slot != NONE) ctdense[(size_t)slot * 32u + li] = cnt[padded(32u * j + li)];
+    }
+  }
   __syncthreads();
   if (!big) {
     // one window: the scanned counters serve as per-cell cursors
@@ -305,11 +617,11 @@ __global__ __launch_bounds__(FT) void k_part_fine(const Rec* __restrict__ rec, u
 // window are staged in LDS and stored as full lines like everywhere else.
 template <int GD, bool GROUPED>
 __global__ __launch_bounds__(FT) void k_part_fine_windows(const Rec* __restrict__ rec, const uint32_t* __restrict__ rk,
-                                                         const uint32_t* __restrict__ base, const uint32_t* __restrict__ total,
-                                                         uint32_t nchunk, uint32_t B, GridP g,
+                                                         const uint32_t* __restrict__ bstart, uint32_t bstride,
+                                                         const uint32_t* __restrict__ total, uint32_t B, GridP g,
                                                          const uint32_t* __restrict__ ord, const uint8_t* __restrict__ in_classed,
-                                                         const int32_t* __restrict__ group,
-                                                         const uint32_t* __restrict__ cellstart, float* __restrict__ sorted32,
+                                                         const int32_t* __restrict__ group, CellTab ct,
+                                                         float* __restrict__ sorted32,
                                                          uint32_t* __restrict__ sord, uint32_t* __restrict__ sidx_out,
                                                          int32_t* __restrict__ sgroup, uint8_t* __restrict__ flags,
                                                          uint32_t* __restrict__ pos, const uint2* __restrict__ queue,
@@ -323,13 +635,13 @@ __global__ __launch_bounds__(FT) void k_part_fine_windows(const Rec* __restrict_
   for (uint32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
     const uint2 q = queue[qi];
     const uint32_t b = q.x, w0 = q.y;
-    const uint32_t s = base[(size_t)b * nchunk];
-    const uint32_t e = (b + 1 < B) ? base[(size_t)(b + 1) * nchunk] : *total;
+    uint32_t s, e;
+    bucket_range(bstart, bstride, total, b, B, s, e);
     const uint32_t m = e - s;
     for (uint32_t j = s + threadIdx.x; j < e; j += FT) {
       const Rec r = rec[j];
       uint32_t i;
-      const uint32_t p = cellstart[rec_cell<GD>(r, g, i)] + rk[j] - s - w0;  // wraps below the window
+      const uint32_t p = ct_start(ct, rec_cell<GD>(r, g, i)) + rk[j] - s - w0;  // wraps below the window
       if (p < WCAP) stage_put<GD>(s32, sidx, p, r, i);
     }
     __syncthreads();
@@ -464,13 +776,13 @@ template <int GD, bool GROUPED>
 int build(vcp_ctx* ctx, const GridBuildArgs& a) {
   hipStream_t st = ctx->stream;
   const PartGeom pg = part_geom(a.n, a.g.ncells);
-  const size_t nc = (size_t)pg.B * pg.nchunk;
+  const size_t nc = (size_t)pg.NS * pg.nchunk;
   VCP_TRY(vcp_ensure(ctx, ctx->b_hist, (nc + 8) * 4));
   VCP_TRY(vcp_ensure(ctx, ctx->b_rec, (size_t)a.n * sizeof(Rec)));
   uint32_t* counts = ctx->b_hist.as<uint32_t>();
   uint32_t* total = counts + nc;
   Rec* rec = ctx->b_rec.as<Rec>();
-  const size_t lds_h = (size_t)pg.B * 4;
+  const size_t lds_h = (size_t)pg.NS * 4;
   const uint32_t CPB = 1u << pg.csh;
   const size_t lds_f = ((((size_t)CPB + CPB / 32) + 4) & ~3ull) * 4 + (size_t)wcap(GD) * ((GD == 2 ? 8 : 16) + 4);
   VCP_TRY(allow_lds(ctx, k_part_fine<GD, GROUPED>, lds_f));
@@ -479,24 +791,42 @@ int build(vcp_ctx* ctx, const GridBuildArgs& a) {
   uint32_t* qcount = ctx->b_fineq.as<uint32_t>();
   uint2* queue = reinterpret_cast<uint2*>(ctx->b_fineq.as<char>() + 64);
   vcp_phase(ctx, "part_hist");
+  const uint32_t csh_a = pg.csh + pg.a;  // the coarse passes split by super-bucket
   hipLaunchKernelGGL((k_part_hist<GD, GROUPED>), dim3(pg.nchunk), dim3(PT), lds_h, st, a.d_coords, a.n, a.stride, a.g,
-                     a.d_group, a.glo, a.ghi, pg.csh, pg.B, pg.chunk, pg.nchunk, counts, qcount);
+                     a.d_group, a.glo, a.ghi, csh_a, pg.NS, pg.chunk, pg.nchunk, counts, qcount, a.ctcount);
   VCP_TRY(vcp_exclusive_scan_u32(ctx, counts, counts, (int64_t)nc, total));
   vcp_phase(ctx, "part_scatter");
   hipLaunchKernelGGL((k_part_scatter<GD, GROUPED>), dim3(pg.nchunk), dim3(PT), lds_h, st, a.d_coords, a.n, a.stride, a.g,
-                     a.d_group, a.glo, a.ghi, pg.csh, pg.B, pg.chunk, pg.nchunk, counts, rec, a.pos);
+                     a.d_group, a.glo, a.ghi, csh_a, pg.NS, pg.chunk, pg.nchunk, counts, rec, a.pos);
+  const uint32_t* bstart = counts;
+  uint32_t bstride = pg.nchunk;
+  if (pg.a > 0) {
+    vcp_phase(ctx, "part_split");
+    VCP_TRY(vcp_ensure(ctx, ctx->b_rec2, (size_t)a.n * sizeof(Rec)));
+    VCP_TRY(vcp_ensure(ctx, ctx->b_bstart, ((size_t)pg.B + 2) * 4));
+    hipLaunchKernelGGL(k_part_split<GD>, dim3(pg.NS), dim3(FT), 0, st, rec, ctx->b_rec2.as<Rec>(), counts, total, pg.nchunk,
+                       pg.NS, pg.a, pg.csh, pg.B, a.g, ctx->b_bstart.as<uint32_t>());
+    rec = ctx->b_rec2.as<Rec>();
+    bstart = ctx->b_bstart.as<uint32_t>();
+    bstride = 1;
+  }
   vcp_phase(ctx, "part_fine");
   VCP_TRY(vcp_ensure(ctx, ctx->b_rank, (size_t)a.n * 4));  // ranks inside the cell, written for large buckets only
-  hipLaunchKernelGGL((k_part_fine<GD, GROUPED>), dim3(pg.B), dim3(FT), lds_f, st, rec, ctx->b_rank.as<uint32_t>(), counts,
-                     total, pg.nchunk, pg.B,
-                     pg.csh, a.g, a.d_ord, a.d_in_classed, a.d_group, a.cellstart, a.sorted32, a.sord, a.sidx, a.sgroup,
-                     a.flags, a.pos, queue, qcount);
+  VCP_TRY(vcp_ensure(ctx, ctx->b_bstate, (size_t)pg.B + 16));
+  uint8_t* bstate = ctx->b_bstate.as<uint8_t>();
+  hipLaunchKernelGGL((k_part_fine_small<GD, GROUPED>), dim3(pg.B), dim3(FS), 0, st, rec, bstart, bstride, total, pg.B, pg.csh,
+                     a.g, a.d_ord, a.d_in_classed, a.d_group, a.ctwords, a.ctdense, a.ctcount, bstate, a.sorted32, a.sord,
+                     a.sidx, a.sgroup, a.flags, a.pos);
+  hipLaunchKernelGGL((k_part_fine<GD, GROUPED>), dim3(pg.B), dim3(FT), lds_f, st, rec, ctx->b_rank.as<uint32_t>(), bstart,
+                     bstride, total, pg.B, pg.csh, a.g, a.d_ord, a.d_in_classed, a.d_group, a.ctwords, a.ctdense, a.ctcount,
+                     a.sorted32, a.sord, a.sidx, a.sgroup, a.flags, a.pos, queue, qcount, bstate);
   {
     const size_t lds_w = (size_t)wcap(GD) * ((GD == 2 ? 8 : 16) + 4);
     VCP_TRY(allow_lds(ctx, k_part_fine_windows<GD, GROUPED>, lds_w));
     const unsigned gw = (unsigned)std::min<size_t>(768, (size_t)a.n / wcap(GD) + 1);  // 3 workgroups per CU (48 KB LDS each in 2-D)
+    const CellTab ct{a.ctwords, a.ctdense, a.ctcount + 1};
     hipLaunchKernelGGL((k_part_fine_windows<GD, GROUPED>), dim3(gw), dim3(FT), lds_w, st, rec, ctx->b_rank.as<uint32_t>(),
-                       counts, total, pg.nchunk, pg.B, a.g, a.d_ord, a.d_in_classed, a.d_group, a.cellstart, a.sorted32,
+                       bstart, bstride, total, pg.B, a.g, a.d_ord, a.d_in_classed, a.d_group, ct, a.sorted32,
                        a.sord, a.sidx, a.sgroup, a.flags, a.pos, queue, qcount);
   }
   VCP_HIP(ctx, hipGetLastError());
@@ -504,12 +834,6 @@ int build(vcp_ctx* ctx, const GridBuildArgs& a) {
 }
 
 }  // namespace
-
-bool vcp_grid_partition_fits(int64_t n, uint32_t ncells) {
-  if (getenv("VCP_BUILD_SORT")) return false;  // A/B switch: keep the round-1 sort-based build
-  if (n <= 0) return false;
-  return part_geom(n, ncells).B <= MAXB;
-}
 
 int vcp_grid_build_partition(vcp_ctx* ctx, const GridBuildArgs& a) {
   const bool grouped = a.d_group != nullptr;

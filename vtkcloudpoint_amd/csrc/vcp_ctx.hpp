@@ -41,7 +41,7 @@ struct vcp_ctx {
   std::vector<DevBuf*> bufs;
   DevBuf b_cellcnt, b_cellof, b_rank, b_sorted, b_sidx, b_flags, b_parent, b_minord, b_seedflag,
       b_rootcl, b_clseed, b_scan_tmp, b_misc, b_in0, b_in1, b_in2, b_in3, b_out0, b_out1, b_out2,
-      b_out3, b_icp_part, b_aux0, b_aux1, b_aux2, b_aux3, b_aux4, b_aux5, b_pos, b_labk, b_sgroup, b_wl, b_skey, b_sorttmp, b_hist, b_rec, b_nn_misc, b_nn_cells, b_nn_cid, b_nn_rec, b_nn_cur, b_nbr, b_nboff, b_sorted32, b_self, b_outcur, b_fineq;
+      b_out3, b_icp_part, b_aux0, b_aux1, b_aux2, b_aux3, b_aux4, b_aux5, b_pos, b_labk, b_sgroup, b_wl, b_skey, b_sorttmp, b_hist, b_rec, b_nn_misc, b_nn_cells, b_nn_cid, b_nn_rec, b_nn_cur, b_nbr, b_nboff, b_sorted32, b_self, b_outcur, b_fineq, b_rec2, b_bstart, b_ctw, b_ctd, b_bstate;
   struct BlocksState* blocks = nullptr;  // staged block-partitioned pipeline (blocks.hip)
   struct SlabState* slab = nullptr;      // staged exact multi-GPU DBSCAN (dbscan.hip: vcp_slab_*)
   // timing

@@ -177,6 +177,7 @@ namespace vtkPointCloud
         // MainForm.getClusterFromMotor + DoWork3 + the labelling half of CompleteWork3
         // (FrmMain.cs:1214-1291, :1340-1361, :1442-1520) as one blocking call; returns clusForMerge.
         // partitionOnXY: the twin getClusterFromList (:1136-1213), whose rectangles are cut on (X, Y).
+        // VcpNative.Devices = { 0, 1, ..., 7 } spreads the per-block step over those GPUs (one process, vcp_dbscan_blocks_multi).
         public static List<Point3D> ClusterBlocks(List<Point3D> rawData, double tr, int pts, int ptsInCell,
                                                   bool partitionOnXY, out int clusterAmount)
         {
@@ -191,9 +192,19 @@ namespace vtkPointCloud
             int[] lab = new int[n], blk = new int[n];
             long[] order = new long[Math.Max(n, 1)];
             long m, ev; int rows, cols, kept, del;
-            using (VcpNative.Lease c = VcpNative.Rent())
-                VcpNative.Check(c, VcpNative.vcp_dbscan_blocks_keyed(c.Ctx, key, mot, n, tr, pts, ptsInCell, 3, lab, blk,
-                order, out m, out rows, out cols, out kept, out del, out clusterAmount, out ev));
+            if (VcpNative.Devices.Length > 1)
+            {   // several GPUs: the per-block DBImproved calls (StartCode on pool threads, FrmMain.cs:1356-1359) are split over
+                // VcpNative.Devices by contiguous block ranges; same results, bit for bit
+                lock (VcpNative.MultiLock)
+                    VcpNative.CheckMulti(VcpNative.vcp_dbscan_blocks_multi(VcpNative.Multi, key, mot, n, tr, pts, ptsInCell, 3,
+                        lab, blk, order, out m, out rows, out cols, out kept, out del, out clusterAmount, out ev));
+            }
+            else
+            {
+                using (VcpNative.Lease c = VcpNative.Rent(VcpNative.Devices.Length == 1 ? VcpNative.Devices[0] : VcpNative.Device))
+                    VcpNative.Check(c, VcpNative.vcp_dbscan_blocks_keyed(c.Ctx, key, mot, n, tr, pts, ptsInCell, 3, lab, blk,
+                        order, out m, out rows, out cols, out kept, out del, out clusterAmount, out ev));
+            }
             for (int i = 0; i < n; i++) { rawData[i].clusterId = lab[i]; rawData[i].isClassed = lab[i] != 0; }
             List<Point3D> clusForMerge = new List<Point3D>((int)m);
             for (long t = 0; t < m; t++) clusForMerge.Add(rawData[(int)order[t]]);

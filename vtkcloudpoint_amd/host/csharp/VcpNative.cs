@@ -115,6 +115,48 @@ namespace vtkPointCloud
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_slab_finish(IntPtr ctx, uint[] map_rep, uint[] map_k, long n_tab,
             int[] tab_gid, uint[] tab_seed, uint own_lo, uint own_count, IntPtr d_labels, IntPtr d_is_classed, out long twice);
 
+        // ---- several GPUs from this one process (csrc/multi.hip): what the ThreadPool fan-out of FrmMain.cs:1356-1359
+        // becomes -- one context and one native host thread per listed device, label slices gathered on device 0 ----
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_create_multi(int[] device_ids, int n, out IntPtr multi);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern void vcp_destroy_multi(IntPtr multi);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern IntPtr vcp_multi_last_error(IntPtr multi);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_multi_count(IntPtr multi);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern IntPtr vcp_multi_ctx(IntPtr multi, int i);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_dbscan_blocks_multi(IntPtr multi, double[] key_xy,
+            double[] motor, long n, double eps, int min_pts, int pts_in_cell, int small_max, int[] labels, int[] block_of,
+            long[] merge_order, out long m_out, out int rows, out int cols, out int kept, out int del_sum,
+            out int cluster_amount, out long dist_evals);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_blocks_share_plan(uint[] blockstart, long nblocks, int world, long[] cuts);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_selftest_horn(double[] sums, long nd, double[] V, int use_v, double[] R1, double[] T1);
+
+        // The device set of the multi-GPU calls: created on first use from Devices (default: device 0 only), replaced when
+        // Devices changes, destroyed by Shutdown().  One vcp_multi serves one call at a time (the lock below).
+        public static int[] Devices = new int[] { 0 };
+        static IntPtr multi = IntPtr.Zero;
+        static int[] multiDevices = null;
+        public static readonly object MultiLock = new object();
+        public static IntPtr Multi   // call under lock (MultiLock)
+        {
+            get
+            {
+                bool same = multi != IntPtr.Zero && multiDevices != null && multiDevices.Length == Devices.Length;
+                if (same) for (int i = 0; i < Devices.Length; i++) same &= multiDevices[i] == Devices[i];
+                if (!same)
+                {
+                    if (multi != IntPtr.Zero) { vcp_destroy_multi(multi); multi = IntPtr.Zero; }
+                    if (IntPtr.Size != 8) throw new InvalidOperationException("libvcp is 64-bit only");
+                    int rc = vcp_create_multi(Devices, Devices.Length, out multi);
+                    if (rc != 0) throw new InvalidOperationException("vcp_create_multi: " + Marshal.PtrToStringAnsi(vcp_multi_last_error(IntPtr.Zero)));
+                    multiDevices = (int[])Devices.Clone();
+                }
+                return multi;
+            }
+        }
+        public static void CheckMulti(int rc)
+        {
+            if (rc != 0) throw new InvalidOperationException("vcp error " + rc + ": " + Marshal.PtrToStringAnsi(vcp_multi_last_error(multi)));
+        }
+
         // ---- contexts ---------------------------------------------------------------------------------------------
         // A context (stream + device workspace, ~100 bytes per point of its largest call) serves one call at a time.
         // StartCode runs on ThreadPool threads (FrmMain.cs:1358), which come and go: a context per thread would leak one
@@ -171,6 +213,12 @@ namespace vtkPointCloud
                 foreach (System.Collections.Generic.Stack<IntPtr> st in pool.Values)
                     while (st.Count > 0) vcp_destroy(st.Pop());
                 pool.Clear();
+            }
+            lock (MultiLock)
+            {
+                if (multi != IntPtr.Zero) vcp_destroy_multi(multi);
+                multi = IntPtr.Zero;
+                multiDevices = null;
             }
         }
 

@@ -346,7 +346,10 @@ __device__ __forceinline__ void wl_count(bool isE, bool isB, uint32_t blk, uint3
 __global__ __launch_bounds__(TPB) void k_wl_fill(const uint8_t* __restrict__ flags, CellTab ct, const uint32_t* __restrict__ scanE,
                                                 const uint32_t* __restrict__ scanB, uint32_t* __restrict__ listE,
                                                 uint32_t* __restrict__ listB, uint32_t* __restrict__ seedflag, uint32_t nw,
-                                                unsigned long long* __restrict__ counters) {
+                                                unsigned long long* __restrict__ counters, uint32_t* __restrict__ gtw,
+                                                uint32_t G) {
+  // (grouped calls: the per-group counters of border points queried twice, read by k_border_list / k_group_stats)
+  for (uint32_t g = blockIdx.x * TPB + threadIdx.x; g < G; g += gridDim.x * TPB) gtw[g] = 0u;
   // also: clears the seed bitmap (8 words per workgroup of 256 positions, the tail by workgroup 0) and the counters
   // for the phases that follow
   if (threadIdx.x < 8) {
@@ -1549,11 +1552,16 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   VCP_TRY(vcp_ensure(ctx, ctx->b_misc, (size_t)(rb * 8 + 96) * sizeof(double)));
   double* d_part = ctx->b_misc.as<double>();
   double* d_bounds = d_part + (size_t)rb * 8;
-  hipLaunchKernelGGL((k_bounds<GD, GROUPED>), dim3(rb), dim3(TPB), 0, st, d_coords, n, stride, d_group, glo, ghi, d_part);
-  hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(TPB), 0, st, d_part, rb, d_bounds);
   double* h = reinterpret_cast<double*>(ctx->pinned);
-  VCP_HIP(ctx, hipMemcpyAsync(h, d_bounds, 7 * sizeof(double), hipMemcpyDeviceToHost, st));
-  VCP_HIP(ctx, hipStreamSynchronize(st));
+  if (ext && ext->h_bbox) {  // the caller has seen every point: finite, inside this box
+    for (int a = 0; a < 6; a++) h[a] = ext->h_bbox[a];
+    h[6] = 0.0;
+  } else {
+    hipLaunchKernelGGL((k_bounds<GD, GROUPED>), dim3(rb), dim3(TPB), 0, st, d_coords, n, stride, d_group, glo, ghi, d_part);
+    hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(TPB), 0, st, d_part, rb, d_bounds);
+    VCP_HIP(ctx, hipMemcpyAsync(h, d_bounds, 7 * sizeof(double), hipMemcpyDeviceToHost, st));
+    VCP_HIP(ctx, hipStreamSynchronize(st));
+  }
   const bool all_finite = h[6] == 0.0;
 
   const double thr = (METRIC == VCP_L1_2D) ? eps : l2_threshold(eps);
@@ -1760,7 +1768,6 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   const bool flags_set = d_in_classed != nullptr;
   const bool part_out = !GROUPED && !d_ord && !(ext && ext->slab) && n <= ((int64_t)1 << 27);
   {
-    if (!flags_set && GROUPED) VCP_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)n, st));  // bytes of excluded points
     GridBuildArgs ga;
     ga.d_coords = d_coords;
     ga.n = n;
@@ -1820,7 +1827,7 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   // its readers take off again (scan[0]); the two pad words between the halves are never written and cancel the same way
   VCP_TRY(vcp_exclusive_scan_u32(ctx, blkE, blkE, 2 * ((int64_t)nb + 2), nullptr));
   hipLaunchKernelGGL(k_wl_fill, dim3(nb), dim3(TPB), 0, st, flags, ct, blkE, blkB, wlE.list, wlB.list,
-                     seedflag, nw, counters);
+                     seedflag, nw, counters, GROUPED ? ext->d_group_twice : nullptr, (uint32_t)(GROUPED ? G : 0));
 
   // 6. components of the expanding points
   vcp_phase(ctx, "union");
@@ -1884,7 +1891,6 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
 
   // 7. border rule, then outputs in caller order
   vcp_phase(ctx, "border");
-  if (GROUPED) VCP_HIP(ctx, hipMemsetAsync(ext->d_group_twice, 0, (size_t)G * 4, st));
   hipLaunchKernelGGL(k_labk_rest, dim3(nb), dim3(TPB), 0, st, flags, parent, rootk, labk, ct);
   if (no.NB > 0)
     hipLaunchKernelGGL(k_border_list<GROUPED>, dim3(nbl), dim3(TPB), 0, st, sgroup, flags, sord, rootk, clseed, labk, counters,

@@ -19,6 +19,9 @@ struct DbscanExt {
   // per point (caller order) the smallest ord of its component (0xFFFFFFFF if it is not expanding)
   bool slab = false;
   uint32_t* d_slab_rep = nullptr;
+  // a box the caller already knows to contain every (finite) input point -- {min x, y, z, max x, y, z}: the bounds pass
+  // and its host round trip are skipped (any box is correct: cell indices are clamped; a tight one gives the best grid)
+  const double* h_bbox = nullptr;
 };
 
 // d_* are device pointers; cf_out / dist_evals host pointers (may be null).  stride = doubles per point.

@@ -72,6 +72,8 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=10_000_000)
     ap.add_argument("--metric", default="L1_2D", choices=["L1_2D", "L2_3D"])
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="mode blocks at one rank: run the sharded pipeline's per-rank program anyway (rehearsal)")
     ap.add_argument("--mode", default=None, choices=["single", "blocks", "exact", "replicas"],
                     help="default: single at --gpus 1, blocks at --gpus > 1 (see the module docstring)")
     ap.add_argument("--gather-labels", action="store_true",
@@ -106,24 +108,43 @@ def launch_ranks_if_needed(args):
 # ----------------------------------------------------------------------------------------------------------
 # the blocks workload: used by main() on GPUs and by tests/_bench_worker.py on CPU tensors (gloo + oracle backend)
 # ----------------------------------------------------------------------------------------------------------
+def blocks_step_single(backend, ptr, n, local, labels):
+    """The block pipeline on ONE device: the staged single-device entry points back to back."""
+    bd = BLOCK_DEFAULTS
+    info = backend.blocks_begin(None, bd["eps"], bd["min_pts"], bd["pts_in_cell"], bd["small_max"], device_ptr=ptr, n=n)
+    ev = backend.blocks_cluster_dev(0, info["nblocks"], local.data_ptr())
+    out = backend.blocks_finish_dev(local.data_ptr(), ev, labels.data_ptr())
+    out.update(labels=labels[:n], nblocks=info["nblocks"], block_range=(0, info["nblocks"]), collective_bytes=0,
+               rows=info["rows"], cols=info["cols"])
+    return out
+
+
 def blocks_workload(backend, motor, device, steps, warmup, motor_dev_ptr=None, sync=None, barrier=None,
-                    on_step=None, force_collective=False):
-    """`steps` timed passes of the sharded block pipeline over ONE cloud (every rank holds it).  Returns
-    (seconds for the timed steps on this rank, result of the last step).  sync() drains the device, barrier() is the
-    cross-rank barrier; both bracket the timed region."""
+                    on_step=None, sharded=None):
+    """`steps` timed passes of the block pipeline over ONE cloud (every rank holds it): on several ranks every stage is
+    sharded (distributed.sharded_pipeline: each rank builds, clusters and merges its own share of the blocks; the noise
+    pass runs as exact_slabs; one all-gather of (index, label) pairs); on one rank the single-device entry points.  The
+    job and its result are the same for every N.  Returns (seconds for the timed steps on this rank, result of the last
+    step).  sync() drains the device, barrier() is the cross-rank barrier; both bracket the timed region."""
     import torch
+    import torch.distributed as dist
     from vtkcloudpoint_amd import distributed as D
     n = len(motor)
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if sharded is None:
+        sharded = world > 1
+    ptr = motor_dev_ptr if motor_dev_ptr is not None else motor.ctypes.data
     local = torch.zeros(max(n, 1), dtype=torch.int32, device=device)
     labels = torch.zeros(max(n, 1), dtype=torch.int32, device=device)
     sync = sync or (lambda: None)
     barrier = barrier or (lambda: None)
+    bd = BLOCK_DEFAULTS
 
     def step():
-        return D.sharded_blocks(backend, motor, BLOCK_DEFAULTS["eps"], BLOCK_DEFAULTS["min_pts"],
-                                BLOCK_DEFAULTS["pts_in_cell"], BLOCK_DEFAULTS["small_max"], device=device,
-                                motor_dev_ptr=motor_dev_ptr, local=local, labels=labels,
-                                force_collective=force_collective)
+        if sharded:
+            return D.sharded_pipeline(backend, ptr, n, bd["eps"], bd["min_pts"], bd["pts_in_cell"], bd["small_max"],
+                                      device=device, labels=labels)
+        return blocks_step_single(backend, ptr, n, local, labels)
 
     r = None
     for _ in range(warmup):
@@ -330,6 +351,7 @@ def main():
     phase_ms = {}
     collectives = []
     extra_cfg = {}
+    same_single = None
 
     def record(pairs):
         for name, ms in pairs:
@@ -343,42 +365,45 @@ def main():
             dist.barrier()
 
     if mode == "blocks":
-        class Timed:  # the staged engine resets its phase timers per call: collect after each stage
-            def __init__(self, c):
-                self.c, self.on = c, False
-
-            def blocks_begin(self, *a, **k):
-                r = self.c.blocks_begin(*a, **k)
-                if self.on:
-                    record([("begin:" + nm, ms) for nm, ms in self.c.timing()])
-                return r
-
-            def blocks_share(self, *a):
-                return self.c.blocks_share(*a)
-
-            def blocks_cluster_dev(self, *a):
-                r = self.c.blocks_cluster_dev(*a)
-                if self.on:
-                    record([("cluster:" + nm, ms) for nm, ms in self.c.timing()])
-                return r
-
-            def blocks_finish_dev(self, *a):
-                r = self.c.blocks_finish_dev(*a)
-                if self.on:
-                    record([("finish:" + nm, ms) for nm, ms in self.c.timing()])
-                return r
-        timed = Timed(ctx)
-
-        # warm-up steps run untimed and unrecorded; recording starts with the first timed step
-        timed.on = False
-        dt, last = blocks_workload(timed, coords, dev, 0, args.warmup, motor_dev_ptr=d_coords.data_ptr(), sync=sync,
-                                   barrier=barrier, force_collective=dist is not None)
-        timed.on = True
-        dt, last = blocks_workload(timed, coords, dev, args.steps, 0, motor_dev_ptr=d_coords.data_ptr(), sync=sync,
-                                   barrier=barrier, force_collective=dist is not None)
+        # the timed loop runs without per-phase events; one more step afterwards, untimed, collects them
+        ctx.timing_enable(False)
+        shd = True if args.force_sharded else None
+        dt, last = blocks_workload(ctx, coords, dev, 0, args.warmup, motor_dev_ptr=d_coords.data_ptr(), sync=sync,
+                                   barrier=barrier, sharded=shd)
+        dt, last = blocks_workload(ctx, coords, dev, args.steps, 0, motor_dev_ptr=d_coords.data_ptr(), sync=sync,
+                                   barrier=barrier, sharded=shd)
         cf, total_points = last["cluster_amount"], n
-        if dist:
-            collectives.append({"op": "all_gather_into_tensor(int32 block-major labels + op counter)",
+        if rank == 0:
+            # the SAME job on one GPU (the single-device entry points), outside the timed region: what the N-GPU line
+            # above is a speed-up of
+            loc1 = torch.zeros(n, dtype=torch.int32, device=dev)
+            lab1 = torch.zeros(n, dtype=torch.int32, device=dev)
+            best = None
+            for _ in range(4):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                r1 = blocks_step_single(ctx, d_coords.data_ptr(), n, loc1, lab1)
+                e = time.perf_counter() - t1
+                best = e if best is None else min(best, e)
+            same = bool(torch.equal(lab1[:n], last["labels"])) and r1["cluster_amount"] == last["cluster_amount"]
+            same_single = {"ms": best * 1e3, "labels_identical_to_the_timed_run": same}
+            # phases of the stages (library hipEvents), one untimed pass
+            ctx.timing_enable(True)
+            bd = BLOCK_DEFAULTS
+            info = ctx.blocks_begin(None, bd["eps"], bd["min_pts"], bd["pts_in_cell"], bd["small_max"],
+                                    device_ptr=d_coords.data_ptr(), n=n)
+            evb = ctx.blocks_cluster_dev(0, info["nblocks"], loc1.data_ptr())
+            record([("cluster:" + nm, ms) for nm, ms in ctx.timing()])
+            ctx.blocks_finish_dev(loc1.data_ptr(), evb, lab1.data_ptr())
+            record([("finish:" + nm, ms) for nm, ms in ctx.timing()])
+            del loc1, lab1
+        if dist and world > 1:
+            collectives.append({"op": "all_gather of 9 int64 per rank (cluster counts, quirk flags, op counters, sizes)",
+                                "backend": "nccl (RCCL)", "per_step": 1})
+            collectives.append({"op": "noise pass as exact_slabs over the ranks' zero lists: x-intervals, 2*eps halo "
+                                      "strips, boundary (point, seed) pairs, published ids, twice counters",
+                                "backend": "nccl (RCCL)", "per_step": 5})
+            collectives.append({"op": "all_gather_into_tensor((index, label) int64 pairs, padded to the largest share)",
                                 "backend": "nccl (RCCL)", "bytes_sent_per_rank_per_step": last["collective_bytes"],
                                 "per_step": 1})
         extra_cfg = {"blocks": last["nblocks"], "block_range_rank0": list(last["block_range"]),
@@ -497,7 +522,7 @@ def main():
         if mode == "blocks":
             # the per-block engine call is this rank's share of the points; begin / finish phases cover all of them
             eng = {k.split(":", 1)[1]: v for k, v in avg.items() if k.startswith("cluster:")}
-            roof = roofline_of(eng, (last["local"].numel() // world) if world > 1 else n, dim, args.metric)
+            roof = roofline_of(eng, n, dim, args.metric)  # (the untimed single-device pass: all n points)
         else:
             roof = roofline_of(avg, n, dim, args.metric)
         if roof:
@@ -511,10 +536,11 @@ def main():
             "single": "C4: %d-pt cloud (half uniform background, %d Gaussian blobs), one monolithic DBImproved.dbscan, "
                       "metric %s, eps %g, minPts %d" % (n, n // 50_000, args.metric, eps, min_pts),
             "blocks": "C4: ONE %d-pt cloud, block-partitioned DBImproved pipeline at the reference defaults (eps %g, "
-                      "minPts %d, %d points per block), per-block step sharded over %d GPU(s) by contiguous block "
-                      "ranges, RCCL all-gather of the block-major int32 labels inside the timed region, CompleteWork3 "
-                      "on every rank" % (n, BLOCK_DEFAULTS["eps"], BLOCK_DEFAULTS["min_pts"],
-                                         BLOCK_DEFAULTS["pts_in_cell"], world),
+                      "minPts %d, %d points per block) on %d GPU(s): every rank repeats the streaming passes that decide "
+                      "the partition and builds, clusters and merges its own share of the blocks; noise pass as exact "
+                      "slabs; RCCL all-gather of (index, label) pairs inside the timed region; every rank ends with the "
+                      "full label array" % (n, BLOCK_DEFAULTS["eps"], BLOCK_DEFAULTS["min_pts"],
+                                            BLOCK_DEFAULTS["pts_in_cell"], world),
             "exact": "C4 family: %d-pt x-slab per GPU of one cloud, exact monolithic DBImproved.dbscan result (2*eps "
                      "halo + boundary union over RCCL, labels stay on the owning rank), metric %s, eps %g, minPts %d"
                      % (n, args.metric, eps, min_pts),
@@ -536,6 +562,12 @@ def main():
         }
         if halo is not None:
             out["config"]["halo_points_rank0"] = halo
+        if same_single is not None:
+            # the job of the line above through the single-device entry points on rank 0's GPU, outside the timed
+            # region: the N = 1 point of the same workload, measured in this very run
+            out["single_gpu_same_workload_ms"] = same_single["ms"]
+            out["speedup_vs_single_gpu_same_workload"] = same_single["ms"] / ms_per_step
+            out["labels_identical_to_single_gpu_run"] = same_single["labels_identical_to_the_timed_run"]
 
     # ---- side measurements on rank 0 at N=1 -----------------------------------------------------------
     extras = rank == 0 and world == 1 and not args.no_extras

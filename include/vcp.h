@@ -181,6 +181,38 @@ int vcp_blocks_finish_dev(vcp_ctx* ctx, const int32_t* d_local, int64_t evals_bl
                           int64_t* m_out, int32_t* kept, int32_t* del_sum, int32_t* cluster_amount,
                           int64_t* dist_evals);
 
+/* The same pipeline with EVERY stage sharded (one process and one context per GPU; every rank holds the cloud, or at
+ * least can read it): the ranks repeat only the streaming passes that decide the partition, build, cluster and merge
+ * their own share of the blocks, and exchange a few words plus the final (index, label) pairs -- driver:
+ * vtkcloudpoint_amd/distributed.py: sharded_pipeline; result = vcp_dbscan_blocks, bit for bit.
+ *   plan      bounds, first block (FrmMain.cs:1224-1258), block of every point and the population of every SUPER-BUCKET
+ *             (2^k consecutive block ids, *nsuper of them): identical on every rank
+ *   cuts      cuts [world + 1]: first super-bucket of every rank, balanced on the point count (host arithmetic)
+ *   build     the block-major list of the super-buckets [super_lo, super_hi) only (:1259-1285): blocks
+ *             [*block_lo, *block_hi), *m_loc points in them, *n_loc points in all (the last share also holds the
+ *             points in no block)
+ *   cluster   vcp_blocks_cluster_dev on [*block_lo, *block_hi), d_local [m_loc]
+ *   local     CompleteWork3 inside the share (:1442-1504): info = {clusters, kept ones, error (the C# would throw),
+ *             request (the demotion quirk of :1485-1488 reaches the last entry of an EARLIER share), the share has a
+ *             non-empty block, its last entry still carries a label, m_loc, n_loc}
+ *   -- exchange: kept offsets; whose last entry is zeroed (the nearest earlier share with a non-empty block) --
+ *   zero      zero_last != 0: zero that entry; the zero list of the share (:1510-1515): *z_count points
+ *   zcoords   their coordinates [z_count * 2] in zero-list order (swap_xy: as (y, x); shares are bands in y)
+ *   -- the global noise pass over all shares' zero lists: vcp_slab_* (exact DBSCAN over several GPUs), cf preset --
+ *   pairs     d_pairs [n_loc] = (original index << 32 | final label): kept clusters + kept_offset, noise points with
+ *             d_zlab [z_count] (their labels from the noise pass), points in no block 0
+ *   scatter   d_labels[index] = label for count pairs (any rank's), indices < n */
+int vcp_blocks_plan_dev(vcp_ctx* ctx, const double* d_key_xy, const double* d_motor, int64_t n, double eps, int min_pts,
+                        int pts_in_cell, int small_max, int32_t* rows, int32_t* cols, int64_t* nblocks, int64_t* nsuper);
+int vcp_blocks_plan_cuts(vcp_ctx* ctx, int world, int64_t* cuts);
+int vcp_blocks_build_dev(vcp_ctx* ctx, int64_t super_lo, int64_t super_hi, int32_t* block_lo, int32_t* block_hi,
+                         int64_t* m_loc, int64_t* n_loc);
+int vcp_blocks_finish_local_dev(vcp_ctx* ctx, const int32_t* d_local, int64_t info[8]);
+int vcp_blocks_finish_zero_dev(vcp_ctx* ctx, int zero_last, int64_t* z_count);
+int vcp_blocks_finish_zcoords_dev(vcp_ctx* ctx, int swap_xy, double* d_zcoords);
+int vcp_blocks_finish_pairs_dev(vcp_ctx* ctx, int32_t kept_offset, const int32_t* d_zlab, int64_t* d_pairs);
+int vcp_scatter_pairs_dev(vcp_ctx* ctx, const int64_t* d_pairs, int64_t count, int64_t n, int32_t* d_labels);
+
 /* -- several GPUs from ONE process -----------------------------------------------------------
  * The reference fans its blocks out from one process (ThreadPool.QueueUserWorkItem(StartCode, cells[i]) per block,
  * FrmMain.cs:1356-1359) and merges on the UI thread (CompleteWork3, :1442-1520).  vcp_multi is the drop-in form of

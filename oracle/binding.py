@@ -435,3 +435,155 @@ class StagedSlab:
                                    C.c_uint32(own_count), _p(labels, C.c_int32),
                                    None if classed is None else _p(classed, C.c_uint8), C.byref(tw)))
         return tw.value
+
+
+class StagedPipeline(StagedSlab):
+    """CPU stand-in for the product's sharded block pipeline (Context.blocks_plan / blocks_plan_cuts / blocks_build /
+    blocks_cluster_dev / blocks_finish_local / blocks_finish_zero / blocks_finish_zcoords / blocks_finish_pairs /
+    scatter_pairs, plus the slab_* methods of StagedSlab for the global noise pass), so that
+    distributed.sharded_pipeline can be exercised on CPU tensors (gloo).  The partition and the per-block DBImproved come
+    from the oracle's C++ (orc_block_partition, orc_block_cluster); the per-share CompleteWork3 (FrmMain.cs:1442-1504)
+    is restated here in plain numpy / Python loops.  What the tests compare against is orc_block_pipeline, the whole
+    single-process pipeline.  Pointers are host addresses; a super-bucket is one block here."""
+
+    def __init__(self):
+        super().__init__()
+        self.p = None
+
+    def blocks_plan(self, d_motor, n, eps, min_pts, pts_in_cell, small_max=3, d_key=None):
+        motor = np.ctypeslib.as_array(C.cast(d_motor, C.POINTER(C.c_double)), shape=(n, 2)).copy()
+        block_of = np.zeros(n, np.int32)
+        raw = np.zeros(max(n, 1), np.int64)
+        bl = np.zeros(max(n, 1), np.int64)
+        rows, cols, m = C.c_int32(0), C.c_int32(0), C.c_int64(0)
+        _chk(lib().orc_block_partition(_p(motor, C.c_double), C.c_int64(n), int(pts_in_cell), 0,
+                                       _p(block_of, C.c_int32), _p(raw, C.c_int64), _p(bl, C.c_int64), None,
+                                       C.c_int64(0), C.byref(rows), C.byref(cols), C.byref(m)))
+        nblocks = rows.value * cols.value
+        blockstart = np.zeros(nblocks + 1, np.int64)
+        np.add.at(blockstart, block_of[block_of >= 0].astype(np.int64) + 1, 1)
+        blockstart = np.cumsum(blockstart)
+        dropped = np.nonzero(block_of < 0)[0].astype(np.int64)
+        # "super-bucket" S = block S; the last one (S = nblocks) holds the points in no block
+        sbstart = np.concatenate([blockstart, [n]]).astype(np.int64)
+        self.p = dict(motor=motor, n=n, eps=float(eps), min_pts=int(min_pts), small_max=int(small_max), bl=bl,
+                      blockstart=blockstart, nblocks=nblocks, m=m.value, dropped=dropped, sbstart=sbstart)
+        return dict(rows=rows.value, cols=cols.value, nblocks=nblocks, nsuper=nblocks + 1)
+
+    def blocks_plan_cuts(self, world):
+        p = self.p
+        ns = p["nblocks"] + 1
+        cuts = [0]
+        for r in range(1, world):
+            target = (p["n"] * r) // world
+            cuts.append(max(cuts[-1], int(np.searchsorted(p["sbstart"][:ns], target, side="left"))))
+        cuts.append(ns)
+        return cuts
+
+    def blocks_build(self, super_lo, super_hi):
+        p = self.p
+        nb = p["nblocks"]
+        lo, hi = min(super_lo, nb), min(super_hi, nb)
+        p.update(b_lo=lo, b_hi=hi, has_dropped=super_hi == nb + 1 and super_lo <= nb)
+        m = int(p["blockstart"][hi] - p["blockstart"][lo])
+        n_loc = m + (len(p["dropped"]) if p["has_dropped"] else 0)
+        p.update(m_loc=m, n_loc=n_loc)
+        return dict(block_lo=lo, block_hi=hi, m=m, n_loc=n_loc)
+
+    def blocks_cluster_dev(self, block_lo, block_hi, ptr):
+        p = self.p
+        full = np.zeros(max(p["m"], 1), np.int32)
+        ev = C.c_int64(0)
+        _chk(lib().orc_block_cluster(_p(p["motor"], C.c_double), _p(p["bl"], C.c_int64),
+                                     _p(p["blockstart"], C.c_int64), C.c_int64(block_lo), C.c_int64(block_hi),
+                                     C.c_double(p["eps"]), p["min_pts"], 1, _p(full, C.c_int32), C.byref(ev)))
+        local = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int32)), shape=(max(p["m_loc"], 1),))
+        s0 = int(p["blockstart"][p["b_lo"]])
+        local[: p["m_loc"]] = full[s0: s0 + p["m_loc"]]
+        return ev.value
+
+    def blocks_finish_local(self, local_ptr):
+        """CompleteWork3 inside the share: FrmMain.cs:1449-1459 (order by local id, stable), :1460-1504 (renumber, demote
+        a cluster of <= small_max points when the next id shows up -- clusLen counts one too many for the first cluster of a
+        block without noise, the last cluster of a block is never checked, and demoting that over-counted first cluster
+        also zeroes the entry in front of the block)."""
+        p = self.p
+        m = p["m_loc"]
+        local = np.ctypeslib.as_array(C.cast(local_ptr, C.POINTER(C.c_int32)), shape=(max(m, 1),))[:m].copy()
+        s0 = int(p["blockstart"][p["b_lo"]])
+        newlab = np.zeros(m, np.int32)
+        order = np.zeros(m, np.int64)  # final order: share-relative positions
+        kept = clusters = err = req = 0
+        last_block_end = None  # final-order position (exclusive) of the end of the last non-empty block so far
+        for b in range(p["b_lo"], p["b_hi"]):
+            a, e = int(p["blockstart"][b]) - s0, int(p["blockstart"][b + 1]) - s0
+            if e == a:
+                continue
+            ids = local[a:e]
+            o = np.argsort(ids, kind="stable")
+            order[a:e] = a + o
+            K = int(ids.max())
+            zb = int((ids == 0).sum())
+            sizes = np.bincount(ids, minlength=K + 1)
+            for k in range(1, K + 1):
+                eff = int(sizes[k]) + (1 if (zb == 0 and k == 1) else 0)
+                demoted = k < K and eff <= p["small_max"]
+                clusters += 1
+                if demoted:
+                    if zb == 0 and k == 1:
+                        if last_block_end is None:
+                            if p["b_lo"] == 0:
+                                err += 1
+                            else:
+                                req = 1
+                        else:
+                            newlab[order[last_block_end - 1]] = 0
+                else:
+                    kept += 1
+                    newlab[a + np.nonzero(ids == k)[0]] = kept
+            last_block_end = e
+        nonempty = last_block_end is not None
+        last_nonzero = bool(nonempty and newlab[order[last_block_end - 1]] != 0)
+        p.update(newlab=newlab, order=order, last_pos=(int(order[last_block_end - 1]) if nonempty else -1))
+        return dict(clusters=clusters, kept=kept, err=err, req=req, nonempty=int(nonempty),
+                    last_nonzero=int(last_nonzero), m=m, n_loc=p["n_loc"])
+
+    def blocks_finish_zero(self, zero_last):
+        p = self.p
+        if zero_last and p["last_pos"] >= 0:
+            p["newlab"][p["last_pos"]] = 0
+        inorder = p["newlab"][p["order"]] if p["m_loc"] else np.zeros(0, np.int32)
+        p["zpos"] = p["order"][inorder == 0]  # the zero list, in final order (FrmMain.cs:1510-1515)
+        return int(len(p["zpos"]))
+
+    def blocks_finish_zcoords(self, ptr, swap_xy=True):
+        p = self.p
+        z = len(p["zpos"])
+        if z == 0:
+            return
+        s0 = int(p["blockstart"][p["b_lo"]])
+        xy = p["motor"][p["bl"][s0 + p["zpos"]]]
+        out = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(z, 2))
+        out[:] = xy[:, ::-1] if swap_xy else xy
+
+    def blocks_finish_pairs(self, kept_offset, zlab_ptr, pairs_ptr):
+        p = self.p
+        m, n_loc = p["m_loc"], p["n_loc"]
+        s0 = int(p["blockstart"][p["b_lo"]])
+        lab = p["newlab"].astype(np.int64)
+        lab[lab > 0] += kept_offset
+        z = len(p["zpos"])
+        if z:
+            zlab = np.ctypeslib.as_array(C.cast(zlab_ptr, C.POINTER(C.c_int32)), shape=(z,))
+            lab[p["zpos"]] = zlab
+        idx = p["bl"][s0: s0 + m].astype(np.int64)
+        if p["has_dropped"]:
+            idx = np.concatenate([idx, p["dropped"]])
+            lab = np.concatenate([lab, np.zeros(len(p["dropped"]), np.int64)])
+        out = np.ctypeslib.as_array(C.cast(pairs_ptr, C.POINTER(C.c_int64)), shape=(max(n_loc, 1),))
+        out[:n_loc] = (idx << 32) | (lab & 0xFFFFFFFF)
+
+    def scatter_pairs(self, pairs_ptr, count, n, labels_ptr):
+        pr = np.ctypeslib.as_array(C.cast(pairs_ptr, C.POINTER(C.c_int64)), shape=(count,))
+        labels = np.ctypeslib.as_array(C.cast(labels_ptr, C.POINTER(C.c_int32)), shape=(n,))
+        labels[(pr >> 32).astype(np.int64)] = (pr & 0xFFFFFFFF).astype(np.int64).astype(np.int32)

@@ -1,6 +1,6 @@
 """Worker for tests/test_bench_path_gloo.py: one rank of a gloo group running bench.py's OWN multi-GPU step
-(bench.blocks_workload -> distributed.sharded_blocks -> allgather_known) on CPU tensors, with the oracle's staged block
-pipeline standing in for the HIP context.  Checks every rank's final labels against the single-process pipeline."""
+(bench.blocks_workload -> distributed.sharded_pipeline: every stage sharded) on CPU tensors, with the oracle-backed
+stand-in for the HIP context.  Checks every rank's final labels against the single-process pipeline."""
 import json
 import os
 import sys
@@ -21,8 +21,8 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     motor = synth.config_cloud(80_000, seed=77)["motor"]
-    dt, r = bench.blocks_workload(O.StagedBlocks(), motor, "cpu", steps=2, warmup=1, barrier=dist.barrier,
-                                  force_collective=True)
+    motor = np.ascontiguousarray(motor)
+    dt, r = bench.blocks_workload(O.StagedPipeline(), motor, "cpu", steps=2, warmup=1, barrier=dist.barrier)
     bd = bench.BLOCK_DEFAULTS
     ref = O.block_pipeline(motor, bd["eps"], bd["min_pts"], bd["pts_in_cell"], bd["small_max"])
     res = dict(labels_equal=bool(np.array_equal(r["labels"].numpy(), ref["labels"])),

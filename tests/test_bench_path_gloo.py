@@ -1,5 +1,6 @@
-"""The code path `bench.py --gpus N` times at N > 1 (ONE cloud, block ranges per rank, one all-gather of the
-block-major labels, CompleteWork3 on every rank), run with world_size 2 and 3 over gloo on CPU tensors."""
+"""The code path `bench.py --gpus N` times at N > 1 (ONE cloud; every rank builds, clusters and merges its own share of
+the blocks; noise pass as exact slabs; one all-gather of (index, label) pairs), run with world_size 2 and 3 over gloo on
+CPU tensors."""
 import json
 import os
 import subprocess

@@ -28,7 +28,9 @@ SYMBOLS = [
     "vcp_slab_begin", "vcp_slab_comps", "vcp_slab_finish", "vcp_release_workspace", "vcp_selftest_scan_dev",
     "vcp_centroids_weighted", "vcp_dbscan_blocks_keyed", "vcp_blocks_begin_keyed", "vcp_blocks_begin_keyed_dev",
     "vcp_selftest_horn", "vcp_create_multi", "vcp_destroy_multi", "vcp_multi_last_error", "vcp_multi_count",
-    "vcp_multi_ctx", "vcp_dbscan_blocks_multi", "vcp_blocks_share_plan",
+    "vcp_multi_ctx", "vcp_dbscan_blocks_multi", "vcp_blocks_share_plan", "vcp_blocks_plan_dev", "vcp_blocks_plan_cuts",
+    "vcp_blocks_build_dev", "vcp_blocks_finish_local_dev", "vcp_blocks_finish_zero_dev", "vcp_blocks_finish_zcoords_dev",
+    "vcp_blocks_finish_pairs_dev", "vcp_scatter_pairs_dev",
 ]
 
 
@@ -342,6 +344,48 @@ class Context:
                                               _ptr(d_block_of), _ptr(d_merge_order), C.byref(m), C.byref(kept),
                                               C.byref(dels), C.byref(ca), C.byref(ev)))
         return dict(m=m.value, kept=kept.value, del_sum=dels.value, cluster_amount=ca.value, evals=ev.value)
+
+    # -- the block pipeline with every stage sharded (include/vcp.h; driver: distributed.sharded_pipeline) -----------
+    def blocks_plan(self, d_motor, n, eps, min_pts, pts_in_cell, small_max=3, d_key=None):
+        """The streaming passes that decide the partition (identical on every rank).  d_* are device pointers."""
+        rows, cols = C.c_int32(0), C.c_int32(0)
+        nb, ns = C.c_int64(0), C.c_int64(0)
+        self._chk(lib().vcp_blocks_plan_dev(self._h, _ptr(d_key), _ptr(d_motor), C.c_int64(n), C.c_double(eps),
+                                            int(min_pts), int(pts_in_cell), int(small_max), C.byref(rows), C.byref(cols),
+                                            C.byref(nb), C.byref(ns)))
+        return dict(rows=rows.value, cols=cols.value, nblocks=nb.value, nsuper=ns.value)
+
+    def blocks_plan_cuts(self, world):
+        cuts = (C.c_int64 * (world + 1))()
+        self._chk(lib().vcp_blocks_plan_cuts(self._h, int(world), cuts))
+        return [int(c) for c in cuts]
+
+    def blocks_build(self, super_lo, super_hi):
+        lo, hi = C.c_int32(0), C.c_int32(0)
+        m, nl = C.c_int64(0), C.c_int64(0)
+        self._chk(lib().vcp_blocks_build_dev(self._h, C.c_int64(super_lo), C.c_int64(super_hi), C.byref(lo), C.byref(hi),
+                                             C.byref(m), C.byref(nl)))
+        return dict(block_lo=lo.value, block_hi=hi.value, m=m.value, n_loc=nl.value)
+
+    def blocks_finish_local(self, d_local):
+        info = (C.c_int64 * 8)()
+        self._chk(lib().vcp_blocks_finish_local_dev(self._h, _ptr(d_local), info))
+        keys = ("clusters", "kept", "err", "req", "nonempty", "last_nonzero", "m", "n_loc")
+        return dict(zip(keys, (int(v) for v in info)))
+
+    def blocks_finish_zero(self, zero_last):
+        z = C.c_int64(0)
+        self._chk(lib().vcp_blocks_finish_zero_dev(self._h, int(bool(zero_last)), C.byref(z)))
+        return z.value
+
+    def blocks_finish_zcoords(self, d_zcoords, swap_xy=True):
+        self._chk(lib().vcp_blocks_finish_zcoords_dev(self._h, int(bool(swap_xy)), _ptr(d_zcoords)))
+
+    def blocks_finish_pairs(self, kept_offset, d_zlab, d_pairs):
+        self._chk(lib().vcp_blocks_finish_pairs_dev(self._h, C.c_int32(kept_offset), _ptr(d_zlab), _ptr(d_pairs)))
+
+    def scatter_pairs(self, d_pairs, count, n, d_labels):
+        self._chk(lib().vcp_scatter_pairs_dev(self._h, _ptr(d_pairs), C.c_int64(count), C.c_int64(n), _ptr(d_labels)))
 
     # -- exact DBSCAN over several GPUs: staged engine (all d_* are device pointers) --------------------
     def slab_begin(self, d_coords, n, dim, metric, eps, min_pts, d_noexpand, d_ord, d_rep, d_is_core=None):

@@ -461,16 +461,21 @@ __global__ __launch_bounds__(PT) void k_blk_hist(const double* __restrict__ key,
 __global__ __launch_bounds__(PT) void k_blk_scatter(const double* __restrict__ key, const double* __restrict__ motor, int64_t n,
                                                     double x_Min, double y_Min, uint32_t nblocks, uint32_t fsh, uint32_t NS,
                                                     uint32_t chunk, uint32_t nchunk, const int32_t* __restrict__ blockof,
-                                                    const uint32_t* __restrict__ base, Rec32* __restrict__ rec) {
+                                                    const uint32_t* __restrict__ base, Rec32* __restrict__ rec, uint32_t S_lo,
+                                                    uint32_t S_hi, uint32_t off0) {
+  // only the super-buckets [S_lo, S_hi) are built (a rank's share; everything for a single device); record positions
+  // are relative to the first of them (off0)
   extern __shared__ uint32_t h[];
-  for (uint32_t k = threadIdx.x; k < NS; k += PT) h[k] = base[(size_t)k * nchunk + blockIdx.x];
+  for (uint32_t k = S_lo + threadIdx.x; k < S_hi; k += PT) h[k] = base[(size_t)k * nchunk + blockIdx.x] - off0;
   __syncthreads();
   const int64_t first = (int64_t)blockIdx.x * chunk, last = min(first + (int64_t)chunk, n);
 #pragma unroll 2
   for (int64_t i = first + threadIdx.x; i < last; i += PT) {
+    const int32_t b = blockof[i];
+    const uint32_t sb = (b < 0 ? nblocks : (uint32_t)b) >> fsh;
+    if (sb < S_lo || sb >= S_hi) continue;
     const double2 kv = *reinterpret_cast<const double2*>(key + 2 * i);
     const double2 mv = *reinterpret_cast<const double2*>(motor + 2 * i);
-    const int32_t b = blockof[i];
     Rec32 r;
     r.x = mv.x;
     r.y = mv.y;
@@ -509,15 +514,16 @@ __global__ __launch_bounds__(PT) void k_blk_split(const Rec32* __restrict__ rec,
                                                   uint32_t nchunk, uint32_t NS, uint32_t fsh, uint32_t nblocks,
                                                   uint32_t* __restrict__ blockstart, uint32_t* __restrict__ biglist,
                                                   SelState* __restrict__ st, BigInfo* __restrict__ binfo,
-                                                  uint2* __restrict__ slicelist, Desc* __restrict__ fall) {
+                                                  uint2* __restrict__ slicelist, Desc* __restrict__ fall, uint32_t S_lo,
+                                                  uint32_t S_hi, uint32_t off0) {
   __shared__ uint32_t h[MAXF];
   __shared__ uint32_t wsum[PT / 64];
   __shared__ unsigned long long kmn[VF], kmx[VF];
   __shared__ uint32_t bcnt[VF], bst[VF];
-  const uint32_t S = blockIdx.x, F = 1u << fsh, fm = F - 1u;
+  const uint32_t S = S_lo + blockIdx.x, F = 1u << fsh, fm = F - 1u;
   const bool track = F <= VF;
-  const uint32_t s = base[(size_t)S * nchunk];
-  const uint32_t e = (S + 1 < NS) ? base[(size_t)(S + 1) * nchunk] : *total;
+  const uint32_t s = base[(size_t)S * nchunk] - off0;
+  const uint32_t e = ((S + 1 < NS) ? base[(size_t)(S + 1) * nchunk] : *total) - off0;
   for (uint32_t k = threadIdx.x; k < F; k += PT) h[k] = 0u;
   __syncthreads();
   for (uint32_t j = s + threadIdx.x; j < e; j += PT) atomicAdd(&h[rec[j].blk & fm], 1u);
@@ -563,6 +569,7 @@ __global__ __launch_bounds__(PT) void k_blk_split(const Rec32* __restrict__ rec,
       cum += v[q];
     }
     if (S + 1 == NS && t == 0) blockstart[nblocks + 1u] = e;  // (also when nblocks + 1 is a multiple of F)
+    if (S + 1 == S_hi && S_hi < NS && t == 0) blockstart[S_hi << fsh] = e;  // the end of a rank's share
   }
   __syncthreads();
   for (uint32_t j = s + threadIdx.x; j < e; j += PT) {
@@ -748,7 +755,7 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_blk_sort(const Rec32* __re
                                                                Desc* __restrict__ fall, uint32_t* __restrict__ gcnt,
                                                                KeyPart* __restrict__ stage_g, uint32_t* __restrict__ rk_g,
                                                                double* __restrict__ motor_bm, uint32_t* __restrict__ bl,
-                                                               uint32_t* __restrict__ blk_t) {
+                                                               uint32_t* __restrict__ blk_t, uint32_t b_lo, int has_dropped) {
   constexpr int NT = BIG ? 1024 : 256;
   constexpr uint32_t SBMAX = BIG ? 8192u : 512u;
   constexpr uint32_t PER = SBMAX / NT;
@@ -758,7 +765,7 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_blk_sort(const Rec32* __re
   __shared__ unsigned long long s_k[2];
   __shared__ uint32_t s_i[2];
   __shared__ uint32_t wsum[NT / 64];
-  if (BIG) {  // the points in no block (FrmMain.cs:1266; Tools.cs:512): only their indices are wanted, behind the m others
+  if (BIG && has_dropped) {  // the points in no block (FrmMain.cs:1266; Tools.cs:512): only their indices are wanted, behind the m others
     const uint32_t s = blockstart[nblocks], e = blockstart[nblocks + 1];
     for (uint32_t j = s + blockIdx.x * NT + threadIdx.x; j < e; j += gridDim.x * NT) bl[j] = rec2[j].idx;
   }
@@ -780,7 +787,7 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_blk_sort(const Rec32* __re
         if (e - s > VCP_BIG_BLOCK || e == s) continue;  // (uniform over the workgroup)
       }
     } else {
-      b = blockIdx.x;
+      b = b_lo + blockIdx.x;
       s = blockstart[b];
       e = blockstart[b + 1];
       if (e == s || e - s > VCP_BIG_BLOCK) return;
@@ -965,10 +972,27 @@ int vcp_blocks_ens(vcp_ctx* ctx, DevBuf& b, size_t bytes) {
   return VCP_OK;
 }
 
-int vcp_blocks_partition(vcp_ctx* ctx, BlocksState* s, const double* d_key, const double* d_motor, int64_t n,
-                         int pts_in_cell) {
+namespace {
+// starts of the super-buckets in the list of all n points, dense (the scanned counts hold them at a stride)
+__global__ __launch_bounds__(BT) void k_sb_starts(const uint32_t* __restrict__ base, const uint32_t* __restrict__ total,
+                                                  uint32_t nchunk, uint32_t NS, uint32_t* __restrict__ sbstart) {
+  const uint32_t S = blockIdx.x * BT + threadIdx.x;
+  if (S < NS) sbstart[S] = base[(size_t)S * nchunk];
+  else if (S == NS) sbstart[S] = *total;
+}
+
+}  // namespace
+
+// Stage 1, the same on every rank: bounds, the first block, the block of every point and the population of every
+// super-bucket (streaming passes over the whole list).  want_cuts: also bring the super-bucket starts to the host
+// (vcp_blocks_plan_cuts needs them; a single device building everything does not).
+int vcp_blocks_plan(vcp_ctx* ctx, BlocksState* s, const double* d_key, const double* d_motor, int64_t n, int pts_in_cell,
+                    bool want_cuts) {
   hipStream_t st = ctx->stream;
   const bool keyed = d_key != d_motor;
+  s->built = false;
+  s->d_key = d_key;
+  s->d_motor = d_motor;
   // bounds (FrmMain.cs:1224-1227) and the finiteness check
   const int rb = (int)vcp_blocks(n, BT, 1024);
   VCP_TRY(vcp_blocks_ens(ctx, s->misc, (size_t)(rb * 5 + 64) * 8));
@@ -1001,6 +1025,8 @@ int vcp_blocks_partition(vcp_ctx* ctx, BlocksState* s, const double* d_key, cons
   if (chunk < PCH_MIN) chunk = PCH_MIN;
   chunk = (chunk + PT - 1) / PT * PT;
   const uint32_t nchunk = (uint32_t)((n + chunk - 1) / chunk);
+  s->chunk = (uint32_t)chunk;
+  s->nchunk = nchunk;
 
   // the take-th smallest (d, index) and the extent of the first block (FrmMain.cs:1229-1258)
   s->take = (int)std::min<int64_t>(pts_in_cell, n);
@@ -1026,8 +1052,8 @@ int vcp_blocks_partition(vcp_ctx* ctx, BlocksState* s, const double* d_key, cons
     done = hs->done != 0;
   }
   if (!done) return vcp_fail(ctx, VCP_ERR_HIP, "the selection of the first block did not finish");
-  const unsigned long long key_T = hs->key_T;
-  const uint32_t idx_T = hs->idx_T;
+  s->key_T = hs->key_T;
+  s->idx_T = hs->idx_T;
   s->cell_x = hs->fx_max - s->x_Min;
   s->cell_y = hs->fy_max - s->y_Min;
   const double fr = (s->y_Max - s->y_Min) / s->cell_y, fc = (s->x_Max - s->x_Min) / s->cell_x;
@@ -1039,7 +1065,7 @@ int vcp_blocks_partition(vcp_ctx* ctx, BlocksState* s, const double* d_key, cons
   s->nblocks = (int64_t)s->rows * s->cols;
   if (s->nblocks > ((int64_t)1 << 26)) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "%lld blocks", (long long)s->nblocks);
 
-  // block of every point (FrmMain.cs:1259-1285, Tools.cs:510-513) and the block-major list
+  // block of every point (FrmMain.cs:1259-1285, Tools.cs:510-513) and the population of every super-bucket
   const PartP P{s->x_Min, s->x_Max, s->y_Min, s->y_Max, s->cell_x, s->cell_y, 1.0 / s->cell_x, 1.0 / s->cell_y, s->rows, s->cols};
   const uint32_t nblocks = (uint32_t)s->nblocks;
   const uint64_t nb1 = (uint64_t)nblocks + 1;  // + the points in no block
@@ -1047,22 +1073,61 @@ int vcp_blocks_partition(vcp_ctx* ctx, BlocksState* s, const double* d_key, cons
   while (((nb1 + (1ull << fsh) - 1) >> fsh) > MAXS) fsh++;  // nblocks <= 2^26: 2^fsh <= MAXF
   if ((1u << fsh) > MAXF) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "%lld blocks", (long long)s->nblocks);
   const uint32_t NS = (uint32_t)((nb1 + (1ull << fsh) - 1) >> fsh);
+  s->fsh = fsh;
+  s->NS = NS;
   const size_t nc = (size_t)NS * nchunk;
   VCP_TRY(vcp_blocks_ens(ctx, s->blockof, (size_t)n * 4));
   VCP_TRY(vcp_blocks_ens(ctx, s->counts, (nc + 8) * 4));
-  VCP_TRY(vcp_blocks_ens(ctx, s->rec, (size_t)n * sizeof(Rec32)));
-  VCP_TRY(vcp_blocks_ens(ctx, s->rec2, (size_t)n * sizeof(Rec32)));
-  VCP_TRY(vcp_blocks_ens(ctx, s->stage, (size_t)n * sizeof(KeyPart)));
-  VCP_TRY(vcp_blocks_ens(ctx, s->rank, (size_t)n * 4));
   VCP_TRY(vcp_blocks_ens(ctx, s->blockstart, (size_t)(nb1 + 2) * 4));
-  VCP_TRY(vcp_blocks_ens(ctx, s->bl, (size_t)n * 4));
-  VCP_TRY(vcp_blocks_ens(ctx, s->motor_bm, (size_t)n * 16));
-  VCP_TRY(vcp_blocks_ens(ctx, s->blk_t, (size_t)(n + 1) * 4));
-  VCP_TRY(vcp_blocks_ens(ctx, s->biglist, ((size_t)n / VCP_BIG_BLOCK + 8) * 4));
+  uint32_t* counts = s->counts.as<uint32_t>();
+  uint32_t* total = counts + nc;
+  hipLaunchKernelGGL(k_blk_hist, dim3(nchunk), dim3(PT), (size_t)NS * 4, st, d_key, n, P, s->key_T, s->idx_T, nblocks, fsh, NS,
+                     (uint32_t)chunk, nchunk, s->blockof.as<int32_t>(), counts);
+  VCP_TRY(vcp_exclusive_scan_u32(ctx, counts, counts, (int64_t)nc, total));
+  VCP_HIP(ctx, hipGetLastError());
+  s->h_sbstart.clear();
+  if (want_cuts) {
+    VCP_TRY(vcp_blocks_ens(ctx, s->sbstart, ((size_t)NS + 2) * 4));
+    hipLaunchKernelGGL(k_sb_starts, dim3(vcp_blocks((int64_t)NS + 1, BT)), dim3(BT), 0, st, counts, total, nchunk, NS,
+                       s->sbstart.as<uint32_t>());
+    s->h_sbstart.resize((size_t)NS + 1);
+    VCP_HIP(ctx, hipMemcpyAsync(s->h_sbstart.data(), s->sbstart.p, ((size_t)NS + 1) * 4, hipMemcpyDeviceToHost, st));
+    VCP_HIP(ctx, hipStreamSynchronize(st));
+  }
+  s->planned = true;
+  return VCP_OK;
+}
+
+// Stage 2: the block-major list of the super-buckets [S_lo, S_hi) -- a rank's share, cut at super-bucket boundaries
+// (vcp_blocks_plan_cuts), or everything.  n_loc = the points in that share (known to the caller: n for everything).
+int vcp_blocks_build(vcp_ctx* ctx, BlocksState* s, uint32_t S_lo, uint32_t S_hi, uint32_t off0, int64_t n_loc) {
+  hipStream_t st = ctx->stream;
+  if (!s->planned) return vcp_fail(ctx, VCP_ERR_ARG, "the partition has not been planned");
+  if (S_lo > S_hi || S_hi > s->NS) return vcp_fail(ctx, VCP_ERR_ARG, "share of super-buckets");
+  const int64_t n = s->n;
+  const uint32_t nblocks = (uint32_t)s->nblocks, fsh = s->fsh, NS = s->NS, nchunk = s->nchunk;
+  const size_t nc = (size_t)NS * nchunk;
+  const size_t nl = (size_t)(n_loc > 0 ? n_loc : 1);
+  s->S_lo = S_lo;
+  s->S_hi = S_hi;
+  s->b_lo = (int64_t)S_lo << fsh;
+  s->b_hi = std::min<int64_t>((int64_t)S_hi << fsh, s->nblocks);
+  s->n_loc = n_loc;
+  const bool has_dropped = S_hi == NS;
+  SelState* d_sel = s->sel.as<SelState>();
+  SelState* hs = reinterpret_cast<SelState*>(reinterpret_cast<char*>(ctx->pinned) + 1024);
+  VCP_TRY(vcp_blocks_ens(ctx, s->rec, nl * sizeof(Rec32)));
+  VCP_TRY(vcp_blocks_ens(ctx, s->rec2, nl * sizeof(Rec32)));
+  VCP_TRY(vcp_blocks_ens(ctx, s->stage, nl * sizeof(KeyPart)));
+  VCP_TRY(vcp_blocks_ens(ctx, s->rank, nl * 4));
+  VCP_TRY(vcp_blocks_ens(ctx, s->bl, nl * 4));
+  VCP_TRY(vcp_blocks_ens(ctx, s->motor_bm, nl * 16));
+  VCP_TRY(vcp_blocks_ens(ctx, s->blk_t, (nl + 1) * 4));
   // large blocks: descriptors, slices, sub-ranges (V <= m / 128 each, at least 2) and the general kernel's list
-  const size_t nbig_cap = (size_t)n / VCP_BIG_BLOCK + 8, nvirt_cap = (size_t)n / 64 + 2 * nbig_cap + 64;
+  const size_t nbig_cap = nl / VCP_BIG_BLOCK + 8, nvirt_cap = nl / 64 + 2 * nbig_cap + 64;
+  VCP_TRY(vcp_blocks_ens(ctx, s->biglist, nbig_cap * 4));
   VCP_TRY(vcp_blocks_ens(ctx, s->binfo, nbig_cap * sizeof(BigInfo)));
-  VCP_TRY(vcp_blocks_ens(ctx, s->slicelist, (nbig_cap + (size_t)n / SLICE + 8) * sizeof(uint2)));
+  VCP_TRY(vcp_blocks_ens(ctx, s->slicelist, (nbig_cap + nl / SLICE + 8) * sizeof(uint2)));
   VCP_TRY(vcp_blocks_ens(ctx, s->vlist, nvirt_cap * sizeof(Desc)));
   VCP_TRY(vcp_blocks_ens(ctx, s->fall, (nvirt_cap + nbig_cap) * sizeof(Desc)));
   {
@@ -1082,34 +1147,49 @@ int vcp_blocks_partition(vcp_ctx* ctx, BlocksState* s, const double* d_key, cons
   uint32_t* gcnt = s->gcnt.as<uint32_t>();
   Desc* vlist = s->vlist.as<Desc>();
   Desc* fall = s->fall.as<Desc>();
-  hipLaunchKernelGGL(k_blk_hist, dim3(nchunk), dim3(PT), lds_h, st, d_key, n, P, key_T, idx_T, nblocks, fsh, NS,
-                     (uint32_t)chunk, nchunk, s->blockof.as<int32_t>(), counts);
-  VCP_TRY(vcp_exclusive_scan_u32(ctx, counts, counts, (int64_t)nc, total));
-  hipLaunchKernelGGL(k_blk_scatter, dim3(nchunk), dim3(PT), lds_h, st, d_key, d_motor, n, s->x_Min, s->y_Min, nblocks, fsh, NS,
-                     (uint32_t)chunk, nchunk, s->blockof.as<int32_t>(), counts, rec);
-  hipLaunchKernelGGL(k_blk_split, dim3(NS), dim3(PT), 0, st, rec, rec2, counts, total, nchunk, NS, fsh, nblocks, blockstart,
-                     s->biglist.as<uint32_t>(), d_sel, s->binfo.as<BigInfo>(), s->slicelist.as<uint2>(), fall);
-#define VCP_SORT_ARGS(list) rec2, rec, blockstart, nblocks, list, d_sel, fall, gcnt, s->stage.as<KeyPart>(), \
-                            s->rank.as<uint32_t>(), s->motor_bm.as<double>(), s->bl.as<uint32_t>(), s->blk_t.as<uint32_t>()
-  hipLaunchKernelGGL((k_blk_sort<false, false>), dim3(nblocks), dim3(256), 0, st, VCP_SORT_ARGS(nullptr));
-  const unsigned gsl = (unsigned)std::min<size_t>(2048, nbig_cap + (size_t)n / SLICE);
-  hipLaunchKernelGGL(k_big_count, dim3(gsl), dim3(PT), 0, st, rec2, s->binfo.as<BigInfo>(), s->slicelist.as<uint2>(), d_sel, gcnt);
-  hipLaunchKernelGGL(k_big_scan, dim3((unsigned)std::min<size_t>(1024, nbig_cap)), dim3(BT), 0, st, s->binfo.as<BigInfo>(), d_sel,
-                     gcnt, vlist);
-  hipLaunchKernelGGL(k_big_move, dim3(gsl), dim3(PT), 0, st, rec2, rec, s->binfo.as<BigInfo>(), s->slicelist.as<uint2>(), d_sel,
-                     gcnt);
-  hipLaunchKernelGGL((k_blk_sort<false, true>), dim3((unsigned)std::min<size_t>(8192, nvirt_cap)), dim3(256), 0, st,
-                     VCP_SORT_ARGS(vlist));
-  hipLaunchKernelGGL((k_blk_sort<true, true>), dim3(256), dim3(1024), 0, st, VCP_SORT_ARGS(fall));
+  const uint32_t b_lo = (uint32_t)s->b_lo;
+  const unsigned nbl = (unsigned)std::max<int64_t>(s->b_hi - s->b_lo, 1);
+  if (S_hi > S_lo) {
+    hipLaunchKernelGGL(k_blk_scatter, dim3(nchunk), dim3(PT), lds_h, st, s->d_key, s->d_motor, n, s->x_Min, s->y_Min, nblocks,
+                       fsh, NS, s->chunk, nchunk, s->blockof.as<int32_t>(), counts, rec, S_lo, S_hi, off0);
+    hipLaunchKernelGGL(k_blk_split, dim3(S_hi - S_lo), dim3(PT), 0, st, rec, rec2, counts, total, nchunk, NS, fsh, nblocks,
+                       blockstart, s->biglist.as<uint32_t>(), d_sel, s->binfo.as<BigInfo>(), s->slicelist.as<uint2>(), fall,
+                       S_lo, S_hi, off0);
+#define VCP_SORT_ARGS(list) rec2, rec, blockstart, nblocks, list, d_sel, fall, gcnt, s->stage.as<KeyPart>(),              \
+                            s->rank.as<uint32_t>(), s->motor_bm.as<double>(), s->bl.as<uint32_t>(), s->blk_t.as<uint32_t>(), \
+                            b_lo, has_dropped ? 1 : 0
+    if (s->b_hi > s->b_lo)
+      hipLaunchKernelGGL((k_blk_sort<false, false>), dim3(nbl), dim3(256), 0, st, VCP_SORT_ARGS(nullptr));
+    const unsigned gsl = (unsigned)std::min<size_t>(2048, nbig_cap + nl / SLICE);
+    hipLaunchKernelGGL(k_big_count, dim3(gsl), dim3(PT), 0, st, rec2, s->binfo.as<BigInfo>(), s->slicelist.as<uint2>(), d_sel,
+                       gcnt);
+    hipLaunchKernelGGL(k_big_scan, dim3((unsigned)std::min<size_t>(1024, nbig_cap)), dim3(BT), 0, st, s->binfo.as<BigInfo>(),
+                       d_sel, gcnt, vlist);
+    hipLaunchKernelGGL(k_big_move, dim3(gsl), dim3(PT), 0, st, rec2, rec, s->binfo.as<BigInfo>(), s->slicelist.as<uint2>(),
+                       d_sel, gcnt);
+    hipLaunchKernelGGL((k_blk_sort<false, true>), dim3((unsigned)std::min<size_t>(8192, nvirt_cap)), dim3(256), 0, st,
+                       VCP_SORT_ARGS(vlist));
+    hipLaunchKernelGGL((k_blk_sort<true, true>), dim3(256), dim3(1024), 0, st, VCP_SORT_ARGS(fall));
 #undef VCP_SORT_ARGS
+  }
   VCP_HIP(ctx, hipGetLastError());
-  s->h_blockstart.resize((size_t)nb1 + 1);
-  VCP_HIP(ctx, hipMemcpyAsync(s->h_blockstart.data(), s->blockstart.p, (size_t)(nb1 + 1) * 4, hipMemcpyDeviceToHost, st));
+  // host copy of the share's block starts [b_lo, b_hi] (positions relative to the share)
+  s->h_blockstart.assign((size_t)nblocks + 2, 0u);
+  if (S_hi > S_lo) {
+    const size_t cnt = (size_t)(s->b_hi - s->b_lo) + 1 + (has_dropped ? 1 : 0);
+    VCP_HIP(ctx, hipMemcpyAsync(s->h_blockstart.data() + s->b_lo, blockstart + s->b_lo, cnt * 4, hipMemcpyDeviceToHost, st));
+  }
   VCP_HIP(ctx, hipMemcpyAsync(hs, d_sel, sizeof(SelState), hipMemcpyDeviceToHost, st));
   VCP_HIP(ctx, hipStreamSynchronize(st));
-  s->m = s->h_blockstart[(size_t)s->nblocks];
+  s->m = S_hi > S_lo ? s->h_blockstart[(size_t)s->b_hi] : 0;
   s->nbig = hs->nbig;
   s->virt_clean = true;
-  // the finish stage's workgroup-per-block kernels leave the "block" of the points in no block alone
+  s->built = true;
   return VCP_OK;
+}
+
+int vcp_blocks_partition(vcp_ctx* ctx, BlocksState* s, const double* d_key, const double* d_motor, int64_t n,
+                         int pts_in_cell) {
+  VCP_TRY(vcp_blocks_plan(ctx, s, d_key, d_motor, n, pts_in_cell, false));
+  return vcp_blocks_build(ctx, s, 0u, s->NS, 0u, n);
 }

@@ -59,7 +59,9 @@ __global__ __launch_bounds__(NW == 1 ? BT : 64 * NW) void k_block_stats(const in
                                                                        const uint32_t* __restrict__ blockstart,
                                                                        int64_t nblocks, const uint32_t* __restrict__ biglist,
                                                                        uint32_t* __restrict__ kb, uint32_t* __restrict__ zb,
-                                                                       uint32_t* __restrict__ dmisc) {
+                                                                       uint32_t* __restrict__ dmisc, uint32_t b_lo) {
+  // (blockstart, kb, zb, ... are indexed from the first block of this context's share: b_lo is taken off the global ids
+  // of the list of large blocks only)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (NW == 1 && blockIdx.x == 0 && threadIdx.x < 8) {
     // the finish stage's counters and flags ([2] err, [4] some block has more ids than the LDS table) and the two words
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(NW == 1 ? BT : 64 * NW) void k_block_stats(const in
     b = (int64_t)blockIdx.x * (BT / 64) + w;
     if (b >= nblocks) return;
   } else {
-    b = biglist[blockIdx.x];
+    b = biglist[blockIdx.x] - b_lo;
   }
   const uint32_t s0 = blockstart[b], s1 = blockstart[b + 1];
   if (NW == 1 && s1 - s0 > BIG_BLOCK) return;
@@ -150,7 +152,8 @@ __global__ __launch_bounds__(NW == 1 ? BT : 64 * NW) void k_block_order(const in
                                                                        const uint32_t* __restrict__ biglist,
                                                                        const uint32_t* __restrict__ cstart,
                                                                        uint32_t* __restrict__ csize,
-                                                                       uint32_t* __restrict__ order, uint32_t* __restrict__ ovf) {
+                                                                       uint32_t* __restrict__ order, uint32_t* __restrict__ ovf,
+                                                                       uint32_t b_lo) {
   constexpr int NG = NW == 1 ? BT / 64 : 1;  // blocks per workgroup
   __shared__ uint32_t cnt[NG][CS_CAP + 1];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(NW == 1 ? BT : 64 * NW) void k_block_order(const in
     b = (int64_t)blockIdx.x * NG + w;
     if (b >= nblocks) return;  // whole waves leave together; no workgroup barrier below for NW == 1
   } else {
-    b = biglist[blockIdx.x];
+    b = biglist[blockIdx.x] - b_lo;
   }
   const uint32_t s0 = blockstart[b], s1 = blockstart[b + 1];
   if (NW == 1 && (s0 == s1 || s1 - s0 > BIG_BLOCK)) return;
@@ -235,10 +238,10 @@ __global__ __launch_bounds__(BT) void k_keep(int64_t nblocks, const uint32_t* __
                                             const uint32_t* __restrict__ kb, const uint32_t* __restrict__ zb,
                                             const uint32_t* __restrict__ blockstart, const uint32_t* __restrict__ csize,
                                             int small_max, uint32_t* __restrict__ keep, uint32_t* __restrict__ victim_of,
-                                            uint32_t* __restrict__ err) {
+                                            uint32_t* __restrict__ err, uint32_t b_lo) {
   int64_t b = (int64_t)blockIdx.x * BT + threadIdx.x;
+  if (b == 0) keep[cstart[nblocks]] = keep[cstart[nblocks] + 1] = 0u;  // the scan of keep reads one entry more (also of a share without blocks)
   if (b >= nblocks) return;
-  if (b == 0) keep[cstart[nblocks]] = keep[cstart[nblocks] + 1] = 0u;  // the scan of keep reads one entry more
   uint32_t K = kb[b];
   victim_of[b] = NONE32;
   for (uint32_t k = 1; k <= K; k++) {
@@ -250,21 +253,22 @@ __global__ __launch_bounds__(BT) void k_keep(int64_t nblocks, const uint32_t* __
       // the extra clusForMerge entry that gets zeroed is the last entry of the previous non-empty block
       long long pb = b - 1;
       while (pb >= 0 && blockstart[pb + 1] == blockstart[pb]) pb--;
-      if (pb < 0) atomicAdd(err, 1u);  // clusForMerge[-1]: ArgumentOutOfRangeException
-      else victim_of[b] = (uint32_t)pb;
+      if (pb >= 0) victim_of[b] = (uint32_t)pb;
+      else if (b_lo == 0) atomicAdd(err, 1u);  // clusForMerge[-1]: ArgumentOutOfRangeException
+      else err[3] = 1u;  // ([5] of the stage's words) the entry lies in an earlier rank's share: asked for over the exchange
     }
   }
 }
 __global__ __launch_bounds__(BT) void k_newlab(const int32_t* __restrict__ local, const uint32_t* __restrict__ blk_t,
                                               int64_t m, const uint32_t* __restrict__ cstart,
                                               const uint32_t* __restrict__ keep, const uint32_t* __restrict__ keeprank,
-                                              int32_t* __restrict__ newlab) {
+                                              int32_t* __restrict__ newlab, uint32_t b_lo) {
   int64_t t = (int64_t)blockIdx.x * BT + threadIdx.x;
   if (t >= m) return;
   int32_t l = local[t];
   int32_t out = 0;
   if (l > 0) {
-    uint32_t c = cstart[blk_t[t]] + (uint32_t)l - 1u;
+    uint32_t c = cstart[blk_t[t] - b_lo] + (uint32_t)l - 1u;
     if (keep[c]) out = (int32_t)keeprank[c] + 1;
   }
   newlab[t] = out;
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(BT) void k_compact(const uint32_t* __restrict__ zfl
                                                const uint32_t* __restrict__ order, const uint32_t* __restrict__ bl,
                                                const double* __restrict__ motor_bm, int64_t m, uint32_t Z,
                                                uint32_t* __restrict__ zrank, double* __restrict__ zcoords,
-                                               int64_t* __restrict__ merge_order) {
+                                               int64_t* __restrict__ merge_order, int swap_xy) {
   int64_t u = (int64_t)blockIdx.x * BT + threadIdx.x;
   if (u >= m) return;
   uint32_t t = order[u];
@@ -307,7 +311,9 @@ __global__ __launch_bounds__(BT) void k_compact(const uint32_t* __restrict__ zfl
   if (newlab[t] == 0) {
     zrank[t] = zr;  // where the noise pass will leave this point's label
     // the coordinates in block-major order: t stays inside the point's block, the original index does not
-    *reinterpret_cast<double2*>(zcoords + 2 * (size_t)zr) = *reinterpret_cast<const double2*>(motor_bm + 2 * (size_t)t);
+    // (swap_xy: as (y, x) -- the shares of the ranks are bands in y, and the exact multi-GPU DBSCAN cuts along its first axis)
+    const double2 v = *reinterpret_cast<const double2*>(motor_bm + 2 * (size_t)t);
+    *reinterpret_cast<double2*>(zcoords + 2 * (size_t)zr) = swap_xy ? make_double2(v.y, v.x) : v;
     if (merge_order) merge_order[(m - Z) + zr] = (int64_t)bl[t];
   } else if (merge_order) {
     merge_order[u - zr] = (int64_t)bl[t];
@@ -329,6 +335,56 @@ __global__ __launch_bounds__(BT) void k_final_labels(const int32_t* __restrict__
   labels[bl[t]] = v;
 }
 
+// ---- a rank's share (sharded pipeline) -------------------------------------------------------------------------
+// last non-empty block of the share: is there one, and the entry an EARLIER rank's first block would zero through the
+// clusLen off-by-one (FrmMain.cs:1461-1465 with :1485-1488) -- the last entry, in final order, of that block
+__global__ __launch_bounds__(BT) void k_last_entry(int64_t nbl, const uint32_t* __restrict__ blockstart,
+                                                  const uint32_t* __restrict__ order, const int32_t* __restrict__ newlab,
+                                                  uint32_t* __restrict__ dmisc) {
+  __shared__ int best;
+  if (threadIdx.x == 0) best = -1;
+  __syncthreads();
+  int loc = -1;
+  for (int64_t lb = threadIdx.x; lb < nbl; lb += BT)
+    if (blockstart[lb + 1] > blockstart[lb]) loc = (int)lb;
+  if (loc >= 0) atomicMax(&best, loc);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    dmisc[6] = best >= 0 ? 1u : 0u;
+    dmisc[7] = dmisc[8] = 0u;
+    if (best >= 0) {
+      const uint32_t pos = order[blockstart[best + 1] - 1];
+      dmisc[7] = newlab[pos] != 0 ? 1u : 0u;
+      dmisc[8] = pos;
+    }
+  }
+}
+__global__ void k_zero_one(int32_t* __restrict__ newlab, const uint32_t* __restrict__ dmisc) { newlab[dmisc[8]] = 0; }
+// (original index, final label) of every point of the share: kept clusters shifted by the clusters kept in earlier shares,
+// noise / demoted points with what the global noise pass gave them, points in no block 0
+__global__ __launch_bounds__(BT) void k_pairs(const int32_t* __restrict__ newlab, const int32_t* __restrict__ zlab,
+                                             const uint32_t* __restrict__ zrank, const uint32_t* __restrict__ bl, int64_t m,
+                                             int64_t n_loc, int32_t kept_off, int64_t* __restrict__ pairs) {
+  int64_t t = (int64_t)blockIdx.x * BT + threadIdx.x;
+  if (t >= n_loc) return;
+  int32_t v = 0;
+  if (t < m) {
+    v = newlab[t];
+    if (v > 0) v += kept_off;
+    else if (zlab) v = zlab[zrank[t]];
+  }
+  pairs[t] = (int64_t)(((unsigned long long)bl[t] << 32) | (unsigned long long)(uint32_t)v);
+}
+__global__ __launch_bounds__(BT) void k_scatter_pairs(const int64_t* __restrict__ pairs, int64_t cnt, int64_t n,
+                                                     int32_t* __restrict__ labels, uint32_t* __restrict__ bad) {
+  int64_t t = (int64_t)blockIdx.x * BT + threadIdx.x;
+  if (t >= cnt) return;
+  const unsigned long long p = (unsigned long long)pairs[t];
+  const uint32_t i = (uint32_t)(p >> 32);
+  if ((int64_t)i < n) labels[i] = (int32_t)(uint32_t)p;
+  else *bad = 1u;
+}
+
 unsigned nblk(int64_t n) { return vcp_blocks(n, BT); }
 
 // key_in: the coordinates the PARTITION reads -- (motor_x, motor_y) in getClusterFromMotor (FrmMain.cs:1214-1291,
@@ -347,9 +403,6 @@ int blocks_begin(vcp_ctx* ctx, const double* d_motor_in, bool from_host, const d
   if (!ctx->blocks) ctx->blocks = new BlocksState();
   BlocksState* s = ctx->blocks;
   s->ready = false;
-  s->cov_ok = true;
-  s->cov_hi = 0;
-  s->totalC_acc = 0;
   s->n = n;
   s->eps = eps;
   s->min_pts = min_pts;
@@ -371,6 +424,9 @@ int blocks_begin(vcp_ctx* ctx, const double* d_motor_in, bool from_host, const d
   }
   const double* motor = key_in ? (from_host ? s->pkey.as<double>() : key_in) : motor_own;  // what the partition reads
   VCP_TRY(vcp_blocks_partition(ctx, s, motor, motor_own, n, pts_in_cell));
+  s->cov_ok = true;
+  s->cov_lo = s->cov_hi = s->b_lo;
+  s->totalC_acc = 0;
   if (rows_o) *rows_o = s->rows;
   if (cols_o) *cols_o = s->cols;
   if (m_o) *m_o = s->m;
@@ -386,6 +442,7 @@ int blocks_cluster(vcp_ctx* ctx, int32_t lo, int32_t hi, int32_t* d_local, int64
   if (!s || !s->ready) return vcp_fail(ctx, VCP_ERR_ARG, "vcp_blocks_begin has not run");
   if (hi < 0) hi = (int32_t)s->nblocks;
   if (lo < 0 || hi > s->nblocks || lo > hi) return vcp_fail(ctx, VCP_ERR_ARG, "block range");
+  if (lo < hi && (lo < s->b_lo || hi > s->b_hi)) return vcp_fail(ctx, VCP_ERR_ARG, "block range outside this context's share");
   if (evals_o) *evals_o = 0;
   if (lo == hi) return VCP_OK;
   if (s->m == 0) return VCP_OK;
@@ -418,13 +475,18 @@ int blocks_cluster(vcp_ctx* ctx, int32_t lo, int32_t hi, int32_t* d_local, int64
   return VCP_OK;
 }
 
-int blocks_finish(vcp_ctx* ctx, const int32_t* d_local, int64_t evals_blocks, int32_t* d_labels, int64_t* d_merge_order,
-                  int32_t* kept_o, int32_t* del_o, int32_t* ca_o, int64_t* evals_o) {
+// CompleteWork3 (FrmMain.cs:1442-1520) over this context's share of the blocks, in stages:
+//   local   per block: stable order by local id, renumbering, demotion of small clusters (with the clusLen quirks);
+//           reads back the stage's counters: clusters, kept ones, the error / request flags
+//   zero    (after the ranks have told each other who has to zero whose last entry) the zero list: Z, positions
+//   zcoords the coordinates of the zero list (the input of the global noise pass) and the merge order
+// The single-device call runs them back to back.
+int finish_local(vcp_ctx* ctx, const int32_t* d_local, bool sharded, bool force_sort) {
   BlocksState* s = ctx->blocks;
-  if (!s || !s->ready) return vcp_fail(ctx, VCP_ERR_ARG, "vcp_blocks_begin has not run");
   hipStream_t st = ctx->stream;
-  const int64_t n = s->n, m = s->m, nb = s->nblocks;
-  const uint32_t* blockstart = s->blockstart.as<uint32_t>();
+  const int64_t m = s->m, nb = s->b_hi - s->b_lo;  // blocks of the share
+  const uint32_t b_lo = (uint32_t)s->b_lo;
+  const uint32_t* blockstart = s->blockstart.as<uint32_t>() + s->b_lo;
   VCP_TRY(ens(ctx, s->kb, (size_t)(nb + 2) * 4));
   VCP_TRY(ens(ctx, s->zb, (size_t)(nb + 2) * 4));
   VCP_TRY(ens(ctx, s->cstart, (size_t)(nb + 2) * 4));
@@ -432,19 +494,20 @@ int blocks_finish(vcp_ctx* ctx, const int32_t* d_local, int64_t evals_blocks, in
   uint32_t* kb = s->kb.as<uint32_t>();
   uint32_t* zb = s->zb.as<uint32_t>();
   uint32_t* cstart = s->cstart.as<uint32_t>();
-  uint32_t* dmisc = s->misc.as<uint32_t>();  // [0] total clusters, [1] kept, [2] err, [3] Z, [4] id table overflow
-  const unsigned nbw = (unsigned)((nb + BT / 64 - 1) / (BT / 64));  // one wave per block
-  hipLaunchKernelGGL(k_block_stats<1>, dim3(nbw), dim3(BT), 0, st, d_local, blockstart, nb, nullptr, kb, zb, dmisc);
+  // [0] total clusters, [1] kept, [2] err, [3] Z, [4] id table overflow, [5] request to an earlier share, [6..8] k_last_entry
+  uint32_t* dmisc = s->misc.as<uint32_t>();
+  const unsigned nbw = (unsigned)((std::max<int64_t>(nb, 1) + BT / 64 - 1) / (BT / 64));  // one wave per block
+  hipLaunchKernelGGL(k_block_stats<1>, dim3(nbw), dim3(BT), 0, st, d_local, blockstart, nb, nullptr, kb, zb, dmisc, b_lo);
   if (s->nbig)
     hipLaunchKernelGGL(k_block_stats<16>, dim3(s->nbig), dim3(1024), 0, st, d_local, blockstart, nb,
-                       s->biglist.as<uint32_t>(), kb, zb, dmisc);
+                       s->biglist.as<uint32_t>(), kb, zb, dmisc, b_lo);
   VCP_TRY(vcp_exclusive_scan_u32(ctx, kb, cstart, nb + 1, dmisc));  // cstart[nb] = total clusters
   uint32_t* hp = reinterpret_cast<uint32_t*>(ctx->pinned);
-  // The number of clusters sizes two arrays and a scan.  When this context clustered every block itself (one call or a
-  // sequence of adjoining ranges) the engine has already reported it; otherwise (label slices gathered from other
+  // The number of clusters sizes two arrays and a scan.  When this context clustered every block of the share itself (one
+  // call or a sequence of adjoining ranges) the engine has already reported it; otherwise (label slices gathered from other
   // devices) it is read back here.
   uint32_t totalC;
-  if (s->cov_ok && s->cov_hi == nb) {
+  if (s->cov_ok && s->cov_lo == s->b_lo && s->cov_hi == s->b_hi) {
     totalC = (uint32_t)s->totalC_acc;
   } else {
     VCP_HIP(ctx, hipMemcpyAsync(hp, dmisc, 4, hipMemcpyDeviceToHost, st));
@@ -466,16 +529,14 @@ int blocks_finish(vcp_ctx* ctx, const int32_t* d_local, int64_t evals_blocks, in
   uint32_t* order = s->order.as<uint32_t>();
   VCP_TRY(ens(ctx, s->newlab, (size_t)(m + 1) * 4));
   int32_t* newlab = s->newlab.as<int32_t>();
-  VCP_TRY(ens(ctx, s->zflag, (size_t)(m + 2) * 4));
-  uint32_t* zflag = s->zflag.as<uint32_t>();
-  bool by_sort = getenv("VCP_BLOCKS_ORDER_SORT") != nullptr;  // test switch: the library-sort form
+  bool by_sort = force_sort || getenv("VCP_BLOCKS_ORDER_SORT") != nullptr;  // (the variable: test switch)
   for (;;) {
     if (m > 0 && !by_sort) {
       hipLaunchKernelGGL(k_block_order<1>, dim3(nbw), dim3(BT), 0, st, d_local, blockstart, nb, kb, nullptr, cstart, csize,
-                         order, dmisc + 4);
+                         order, dmisc + 4, b_lo);
       if (s->nbig)
         hipLaunchKernelGGL(k_block_order<16>, dim3(s->nbig), dim3(1024), 0, st, d_local, blockstart, nb, kb,
-                           s->biglist.as<uint32_t>(), cstart, csize, order, dmisc + 4);
+                           s->biglist.as<uint32_t>(), cstart, csize, order, dmisc + 4, b_lo);
     } else if (m > 0) {
       VCP_TRY(ens(ctx, s->tmp0, (size_t)(m + 1) * 8));
       VCP_TRY(ens(ctx, s->tmp1, (size_t)(m + 1) * 8));
@@ -490,35 +551,105 @@ int blocks_finish(vcp_ctx* ctx, const int32_t* d_local, int64_t evals_blocks, in
       VCP_HIP(ctx, hipMemcpyAsync(k1, d_local, (size_t)m * 4, hipMemcpyDeviceToDevice, st));
       VCP_TRY(sort_pairs(ctx, s, k1, k1o, iota, v1o, (size_t)m, bits_for((uint64_t)m)));  // a local id is at most m
       hipLaunchKernelGGL(k_gather_u32, dim3(nblk(m)), dim3(BT), 0, st, blk_t, v1o, m, k2);
-      VCP_TRY(sort_pairs(ctx, s, k2, k1o, v1o, order, (size_t)m, bits_for((uint64_t)nb)));
+      VCP_TRY(sort_pairs(ctx, s, k2, k1o, v1o, order, (size_t)m, bits_for((uint64_t)s->nblocks)));
     }
     hipLaunchKernelGGL(k_keep, dim3(nblk(nb)), dim3(BT), 0, st, nb, cstart, kb, zb, blockstart, csize, s->small_max, keep,
-                       victim_of, dmisc + 2);
+                       victim_of, dmisc + 2, b_lo);
     VCP_TRY(vcp_exclusive_scan_u32(ctx, keep, keeprank, (int64_t)totalC + 1, dmisc + 1));
-    hipLaunchKernelGGL(k_newlab, dim3(nblk(m)), dim3(BT), 0, st, d_local, blk_t, m, cstart, keep, keeprank, newlab);
+    hipLaunchKernelGGL(k_newlab, dim3(nblk(m)), dim3(BT), 0, st, d_local, blk_t, m, cstart, keep, keeprank, newlab, b_lo);
     hipLaunchKernelGGL(k_victims, dim3(nblk(nb)), dim3(BT), 0, st, nb, victim_of, blockstart, order, newlab);
-    // zero list (FrmMain.cs:1510-1515) and merge order
-    hipLaunchKernelGGL(k_zero_flag, dim3(nblk(m)), dim3(BT), 0, st, newlab, order, m, zflag);
-    VCP_TRY(vcp_exclusive_scan_u32(ctx, zflag, zflag, m + 1, dmisc + 3));
-    VCP_HIP(ctx, hipMemcpyAsync(hp, dmisc, 32, hipMemcpyDeviceToHost, st));
+    if (!sharded) break;  // (the single device reads the counters once, after the zero list: finish_zero)
+    hipLaunchKernelGGL(k_last_entry, dim3(1), dim3(BT), 0, st, nb, blockstart, order, newlab, dmisc);
+    VCP_HIP(ctx, hipMemcpyAsync(hp, dmisc, 48, hipMemcpyDeviceToHost, st));
     VCP_HIP(ctx, hipStreamSynchronize(st));
     if (hp[4] == 0 || by_sort) break;
     by_sort = true;  // some block has more than CS_CAP cluster ids: once more, order by the library sort
     VCP_HIP(ctx, hipMemsetAsync(dmisc + 2, 0, 4, st));
+    VCP_HIP(ctx, hipMemsetAsync(dmisc + 5, 0, 4, st));
   }
-  if (hp[0] != totalC) return vcp_fail(ctx, VCP_ERR_ARG, "the label array does not hold what vcp_blocks_cluster_dev produced");
-  if (hp[2] != 0)
+  s->f_by_sort = by_sort;
+  s->f_totalC = totalC;
+  s->f_local = d_local;
+  if (sharded) {
+    if (hp[0] != totalC) return vcp_fail(ctx, VCP_ERR_ARG, "the label array does not hold what vcp_blocks_cluster_dev produced");
+    s->f_kept = hp[1];
+    s->f_err = hp[2];
+    s->f_req = hp[5];
+    s->f_nonempty = hp[6];
+    s->f_last_nonzero = hp[7];
+  }
+  return VCP_OK;
+}
+
+// returns 1 in *again when the single-device pass has to be repeated in the library-sort form
+int finish_zero(vcp_ctx* ctx, bool sharded, int zero_last, bool* again) {
+  BlocksState* s = ctx->blocks;
+  hipStream_t st = ctx->stream;
+  const int64_t m = s->m;
+  uint32_t* dmisc = s->misc.as<uint32_t>();
+  uint32_t* hp = reinterpret_cast<uint32_t*>(ctx->pinned);
+  int32_t* newlab = s->newlab.as<int32_t>();
+  uint32_t* order = s->order.as<uint32_t>();
+  if (again) *again = false;
+  if (sharded && zero_last) hipLaunchKernelGGL(k_zero_one, dim3(1), dim3(1), 0, st, newlab, dmisc);
+  // zero list (FrmMain.cs:1510-1515)
+  VCP_TRY(ens(ctx, s->zflag, (size_t)(m + 2) * 4));
+  uint32_t* zflag = s->zflag.as<uint32_t>();
+  hipLaunchKernelGGL(k_zero_flag, dim3(nblk(m)), dim3(BT), 0, st, newlab, order, m, zflag);
+  VCP_TRY(vcp_exclusive_scan_u32(ctx, zflag, zflag, m + 1, dmisc + 3));
+  VCP_HIP(ctx, hipMemcpyAsync(hp, dmisc, 32, hipMemcpyDeviceToHost, st));
+  VCP_HIP(ctx, hipStreamSynchronize(st));
+  if (!sharded) {
+    if (hp[4] != 0 && !s->f_by_sort) {
+      if (again) *again = true;
+      return VCP_OK;
+    }
+    if (hp[0] != s->f_totalC)
+      return vcp_fail(ctx, VCP_ERR_ARG, "the label array does not hold what vcp_blocks_cluster_dev produced");
+    s->f_kept = hp[1];
+    s->f_err = hp[2];
+  }
+  s->f_Z = hp[3];
+  return VCP_OK;
+}
+
+int finish_zcoords(vcp_ctx* ctx, double* d_zcoords, int64_t* d_merge_order, int swap_xy) {
+  BlocksState* s = ctx->blocks;
+  hipStream_t st = ctx->stream;
+  const int64_t m = s->m;
+  if (m > 0)
+    hipLaunchKernelGGL(k_compact, dim3(nblk(m)), dim3(BT), 0, st, s->zflag.as<uint32_t>(), s->newlab.as<int32_t>(),
+                       s->order.as<uint32_t>(), s->bl.as<uint32_t>(), s->motor_bm.as<double>(), m, s->f_Z,
+                       s->tmp2.as<uint32_t>() /* zrank: free again (it held the identity of the library-sort order) */,
+                       d_zcoords, d_merge_order, swap_xy);
+  VCP_HIP(ctx, hipGetLastError());
+  return VCP_OK;
+}
+
+int blocks_finish(vcp_ctx* ctx, const int32_t* d_local, int64_t evals_blocks, int32_t* d_labels, int64_t* d_merge_order,
+                  int32_t* kept_o, int32_t* del_o, int32_t* ca_o, int64_t* evals_o) {
+  BlocksState* s = ctx->blocks;
+  if (!s || !s->ready) return vcp_fail(ctx, VCP_ERR_ARG, "vcp_blocks_begin has not run");
+  if (s->b_lo != 0 || s->b_hi != s->nblocks)
+    return vcp_fail(ctx, VCP_ERR_ARG, "this context holds a share of the blocks: use the vcp_blocks_finish_*_dev stages");
+  hipStream_t st = ctx->stream;
+  const int64_t n = s->n, m = s->m;
+  bool again = false;
+  VCP_TRY(finish_local(ctx, d_local, false, false));
+  VCP_TRY(finish_zero(ctx, false, 0, &again));
+  if (again) {  // some block has more than CS_CAP cluster ids: once more, order by the library sort
+    VCP_TRY(finish_local(ctx, d_local, false, true));
+    VCP_TRY(finish_zero(ctx, false, 0, nullptr));
+  }
+  if (s->f_err != 0)
     return vcp_fail(ctx, VCP_ERR_INDEX, "clusForMerge index -1 while demoting the first cluster (FrmMain.cs:1487)");
-  const uint32_t kept = hp[1], Z = hp[3];
-  const uint32_t delSum = totalC - kept;
-  VCP_TRY(ens(ctx, s->zlist, (size_t)(Z + 1) * 4));
+  const uint32_t kept = s->f_kept, Z = s->f_Z;
+  const uint32_t delSum = s->f_totalC - kept;
   VCP_TRY(ens(ctx, s->zcoords, (size_t)(Z + 1) * 16));
   VCP_TRY(ens(ctx, s->zlab, (size_t)(Z + 1) * 4));
-  uint32_t* zrank = s->tmp2.as<uint32_t>();  // [m + 1]: free again (it held the identity for the library-sort order)
-  if (m > 0)
-    hipLaunchKernelGGL(k_compact, dim3(nblk(m)), dim3(BT), 0, st, zflag, newlab, order, s->bl.as<uint32_t>(),
-                       s->motor_bm.as<double>(), m, Z, zrank, s->zcoords.as<double>(), d_merge_order);
-  VCP_HIP(ctx, hipGetLastError());
+  VCP_TRY(finish_zcoords(ctx, s->zcoords.as<double>(), d_merge_order, 0));
+  uint32_t* zrank = s->tmp2.as<uint32_t>();
+  int32_t* newlab = s->newlab.as<int32_t>();
   // FrmMain.cs:1507-1516: one DBImproved over all noise, cf preset to the kept-cluster count
   int32_t cf = (int32_t)kept;
   int64_t ev = 0;
@@ -634,6 +765,137 @@ int vcp_blocks_finish_dev(vcp_ctx* ctx, const int32_t* d_local, int64_t evals_bl
     VCP_HIP(ctx, hipMemcpyAsync(d_block_of, s->blockof.p, (size_t)s->n * 4, hipMemcpyDeviceToDevice, ctx->stream));
   VCP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (m_out) *m_out = s->m;
+  return VCP_OK;
+}
+
+// ---- the pipeline with every stage sharded (include/vcp.h) ---------------------------------------------------------
+int vcp_blocks_plan_dev(vcp_ctx* ctx, const double* d_key_xy, const double* d_motor, int64_t n, double eps, int min_pts,
+                        int pts_in_cell, int small_max, int32_t* rows, int32_t* cols, int64_t* nblocks, int64_t* nsuper) {
+  if (!ctx) return VCP_ERR_ARG;
+  if (n > 0 && !d_motor) return vcp_fail(ctx, VCP_ERR_ARG, "null buffer");
+  if (n < 0) return vcp_fail(ctx, VCP_ERR_ARG, "n < 0");
+  if (n == 0) return vcp_fail(ctx, VCP_ERR_EMPTY, "rawData.Min() on an empty list throws (FrmMain.cs:1224)");
+  if (pts_in_cell <= 0) return vcp_fail(ctx, VCP_ERR_EMPTY, "Take(0) then cell.Max() throws (FrmMain.cs:1255)");
+  if (n >= 0x7FFFFFF0LL) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "n beyond 32-bit indexing");
+  VCP_TRY(vcp_bind(ctx));
+  if (!ctx->blocks) ctx->blocks = new BlocksState();
+  BlocksState* s = ctx->blocks;
+  s->ready = false;
+  s->n = n;
+  s->eps = eps;
+  s->min_pts = min_pts;
+  s->small_max = small_max;
+  s->motor_ptr = d_motor;
+  VCP_TRY(vcp_blocks_plan(ctx, s, d_key_xy ? d_key_xy : d_motor, d_motor, n, pts_in_cell, true));
+  if (rows) *rows = s->rows;
+  if (cols) *cols = s->cols;
+  if (nblocks) *nblocks = s->nblocks;
+  if (nsuper) *nsuper = s->NS;
+  return VCP_OK;
+}
+
+int vcp_blocks_plan_cuts(vcp_ctx* ctx, int world, int64_t* cuts) {
+  if (!ctx) return VCP_ERR_ARG;
+  BlocksState* s = ctx->blocks;
+  if (!s || !s->planned || s->h_sbstart.empty()) return vcp_fail(ctx, VCP_ERR_ARG, "vcp_blocks_plan_dev has not run");
+  if (world < 1 || !cuts) return vcp_fail(ctx, VCP_ERR_ARG, "world / cuts");
+  // shares of super-buckets balanced on the point count: rank r starts at the first super-bucket whose first point is
+  // >= n * r / world -- the arithmetic of vcp_blocks_share_plan, one level up
+  return vcp_blocks_share_plan(s->h_sbstart.data(), (int64_t)s->NS, world, cuts);
+}
+
+int vcp_blocks_build_dev(vcp_ctx* ctx, int64_t super_lo, int64_t super_hi, int32_t* block_lo, int32_t* block_hi, int64_t* m_loc,
+                         int64_t* n_loc) {
+  if (!ctx) return VCP_ERR_ARG;
+  VCP_TRY(vcp_bind(ctx));
+  BlocksState* s = ctx->blocks;
+  if (!s || !s->planned || s->h_sbstart.empty()) return vcp_fail(ctx, VCP_ERR_ARG, "vcp_blocks_plan_dev has not run");
+  if (super_lo < 0 || super_hi > (int64_t)s->NS || super_lo > super_hi) return vcp_fail(ctx, VCP_ERR_ARG, "share of super-buckets");
+  const uint32_t off0 = s->h_sbstart[(size_t)super_lo];
+  const int64_t nl = (int64_t)s->h_sbstart[(size_t)super_hi] - (int64_t)off0;
+  VCP_TRY(vcp_blocks_build(ctx, s, (uint32_t)super_lo, (uint32_t)super_hi, off0, nl));
+  const int64_t nb1 = s->nblocks + 1;
+  VCP_TRY(ens(ctx, s->gtwice, (size_t)nb1 * 4));
+  VCP_TRY(ens(ctx, s->gnclus, (size_t)nb1 * 4));
+  s->cov_ok = true;
+  s->cov_lo = s->cov_hi = s->b_lo;
+  s->totalC_acc = 0;
+  s->ready = true;
+  if (block_lo) *block_lo = (int32_t)s->b_lo;
+  if (block_hi) *block_hi = (int32_t)s->b_hi;
+  if (m_loc) *m_loc = s->m;
+  if (n_loc) *n_loc = s->n_loc;
+  return VCP_OK;
+}
+
+int vcp_blocks_finish_local_dev(vcp_ctx* ctx, const int32_t* d_local, int64_t info[8]) {
+  if (!ctx) return VCP_ERR_ARG;
+  VCP_TRY(vcp_bind(ctx));
+  BlocksState* s = ctx->blocks;
+  if (!s || !s->ready) return vcp_fail(ctx, VCP_ERR_ARG, "vcp_blocks_build_dev has not run");
+  if (!info || (s->m > 0 && !d_local)) return vcp_fail(ctx, VCP_ERR_ARG, "null buffer");
+  VCP_TRY(finish_local(ctx, d_local, true, false));
+  info[0] = s->f_totalC;
+  info[1] = s->f_kept;
+  info[2] = s->f_err;
+  info[3] = s->f_req;
+  info[4] = s->f_nonempty;
+  info[5] = s->f_last_nonzero;
+  info[6] = s->m;
+  info[7] = s->n_loc;
+  return VCP_OK;
+}
+
+int vcp_blocks_finish_zero_dev(vcp_ctx* ctx, int zero_last, int64_t* z_count) {
+  if (!ctx) return VCP_ERR_ARG;
+  VCP_TRY(vcp_bind(ctx));
+  BlocksState* s = ctx->blocks;
+  if (!s || !s->ready || !s->f_local) return vcp_fail(ctx, VCP_ERR_ARG, "vcp_blocks_finish_local_dev has not run");
+  VCP_TRY(finish_zero(ctx, true, zero_last, nullptr));
+  if (z_count) *z_count = s->f_Z;
+  return VCP_OK;
+}
+
+int vcp_blocks_finish_zcoords_dev(vcp_ctx* ctx, int swap_xy, double* d_zcoords) {
+  if (!ctx) return VCP_ERR_ARG;
+  VCP_TRY(vcp_bind(ctx));
+  BlocksState* s = ctx->blocks;
+  if (!s || !s->ready || !s->f_local) return vcp_fail(ctx, VCP_ERR_ARG, "vcp_blocks_finish_zero_dev has not run");
+  if (s->f_Z > 0 && !d_zcoords) return vcp_fail(ctx, VCP_ERR_ARG, "null buffer");
+  VCP_TRY(finish_zcoords(ctx, d_zcoords, nullptr, swap_xy));
+  VCP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VCP_OK;
+}
+
+int vcp_blocks_finish_pairs_dev(vcp_ctx* ctx, int32_t kept_offset, const int32_t* d_zlab, int64_t* d_pairs) {
+  if (!ctx) return VCP_ERR_ARG;
+  VCP_TRY(vcp_bind(ctx));
+  BlocksState* s = ctx->blocks;
+  if (!s || !s->ready || !s->f_local) return vcp_fail(ctx, VCP_ERR_ARG, "vcp_blocks_finish_zero_dev has not run");
+  if (s->n_loc > 0 && !d_pairs) return vcp_fail(ctx, VCP_ERR_ARG, "null buffer");
+  if (s->f_Z > 0 && !d_zlab) return vcp_fail(ctx, VCP_ERR_ARG, "null buffer");
+  if (s->n_loc > 0)
+    hipLaunchKernelGGL(k_pairs, dim3(nblk(s->n_loc)), dim3(BT), 0, ctx->stream, s->newlab.as<int32_t>(), d_zlab,
+                       s->tmp2.as<uint32_t>(), s->bl.as<uint32_t>(), s->m, s->n_loc, kept_offset, d_pairs);
+  VCP_HIP(ctx, hipGetLastError());
+  VCP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VCP_OK;
+}
+
+int vcp_scatter_pairs_dev(vcp_ctx* ctx, const int64_t* d_pairs, int64_t count, int64_t n, int32_t* d_labels) {
+  if (!ctx) return VCP_ERR_ARG;
+  VCP_TRY(vcp_bind(ctx));
+  if (count < 0 || n < 0) return vcp_fail(ctx, VCP_ERR_ARG, "count / n");
+  if (count == 0) return VCP_OK;
+  if (!d_pairs || !d_labels) return vcp_fail(ctx, VCP_ERR_ARG, "null buffer");
+  VCP_TRY(vcp_ensure(ctx, ctx->b_misc, 256));
+  uint32_t* bad = ctx->b_misc.as<uint32_t>();
+  VCP_HIP(ctx, hipMemsetAsync(bad, 0, 4, ctx->stream));
+  hipLaunchKernelGGL(k_scatter_pairs, dim3(nblk(count)), dim3(BT), 0, ctx->stream, d_pairs, count, n, d_labels, bad);
+  uint32_t* hp = reinterpret_cast<uint32_t*>(ctx->pinned);
+  VCP_HIP(ctx, hipMemcpyAsync(hp, bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+  VCP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (hp[0]) return vcp_fail(ctx, VCP_ERR_ARG, "a pair names an index beyond n");
   return VCP_OK;
 }
 

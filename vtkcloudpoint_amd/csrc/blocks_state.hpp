@@ -19,12 +19,28 @@ struct BlocksState {
   // partition workspace (blockpart.hip)
   DevBuf sel, cand, counts, rec, rec2, stage, rank, binfo, slicelist, vlist, fall, gcnt;
   bool virt_clean = false;  // gcnt is all zero
+  // the plan (identical on every rank) ...
+  bool planned = false, built = false;
+  const double* d_key = nullptr;
+  const double* d_motor = nullptr;
+  unsigned long long key_T = 0;
+  uint32_t idx_T = 0, fsh = 0, NS = 0, chunk = 0, nchunk = 0;
+  DevBuf sbstart;
+  std::vector<uint32_t> h_sbstart;  // [NS + 1] first point of every super-bucket in the list of all n (vcp_blocks_plan)
+  // ... and the share this context built: super-buckets [S_lo, S_hi) = blocks [b_lo, b_hi), n_loc points of which m fell in
+  // a block; positions in the block-major arrays are relative to the share
+  uint32_t S_lo = 0, S_hi = 0;
+  int64_t b_lo = 0, b_hi = 0, n_loc = 0;
   std::vector<uint32_t> h_blockstart;
   DevBuf biglist;  // blocks of more than BIG_BLOCK points, listed by the partition (device), in no particular order
   uint32_t nbig = 0;
   // blocks [0, cov_hi) have been clustered by this context, in adjoining ranges, and hold totalC_acc clusters
   bool cov_ok = true;
-  int64_t cov_hi = 0, totalC_acc = 0;
+  int64_t cov_lo = 0, cov_hi = 0, totalC_acc = 0;
+  // the finish stage's counters between its parts (blocks.hip: finish_local / finish_zero)
+  bool f_by_sort = false;
+  const int32_t* f_local = nullptr;
+  uint32_t f_totalC = 0, f_kept = 0, f_err = 0, f_req = 0, f_nonempty = 0, f_last_nonzero = 0, f_Z = 0;
   bool ready = false;
 };
 
@@ -40,3 +56,7 @@ int vcp_blocks_ens(vcp_ctx* ctx, DevBuf& b, size_t bytes);
 // round (normally one) and one at the end.
 int vcp_blocks_partition(vcp_ctx* ctx, BlocksState* s, const double* d_key, const double* d_motor, int64_t n,
                          int pts_in_cell);
+// the same in two stages, for ranks that each build a share of the blocks (blockpart.hip)
+int vcp_blocks_plan(vcp_ctx* ctx, BlocksState* s, const double* d_key, const double* d_motor, int64_t n, int pts_in_cell,
+                    bool want_cuts);
+int vcp_blocks_build(vcp_ctx* ctx, BlocksState* s, uint32_t S_lo, uint32_t S_hi, uint32_t off0, int64_t n_loc);

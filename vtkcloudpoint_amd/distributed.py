@@ -210,20 +210,24 @@ class SlabPipeline:
 def gather_rows(t, group=None, fixed=False):
     """All-gather of a tensor whose first dimension differs per rank; returns the list of every rank's
     tensor (padded to the largest for the collective: RCCL/gloo all-gathers want equal sizes).  fixed=True:
-    every rank sends the same shape, no size exchange."""
+    every rank sends the same shape, no size exchange; fixed = a list of every rank's row count: the sizes are
+    known to everybody already (no size exchange either)."""
     rank, world = _world(group)
     if world == 1:
         return [t]
     dev = t.device
     tail = tuple(t.shape[1:])
-    if fixed:
+    if fixed is True:
         recv = t.new_empty((world * t.shape[0],) + tail)
         dist.all_gather_into_tensor(recv, t.contiguous(), group=group)
         return list(recv.split(t.shape[0]))
-    cnt = torch.tensor([t.shape[0]], dtype=torch.int64, device=dev)
-    allc = torch.empty(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(allc, cnt, group=group)
-    allc = allc.cpu().tolist()
+    if isinstance(fixed, (list, tuple)):
+        allc = [int(c) for c in fixed]
+    else:
+        cnt = torch.tensor([t.shape[0]], dtype=torch.int64, device=dev)
+        allc = torch.empty(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allc, cnt, group=group)
+        allc = allc.cpu().tolist()
     width = max(allc)
     if width == 0:
         return [t.new_zeros((0,) + tail) for _ in range(world)]
@@ -412,6 +416,107 @@ def exact_slabs_local(backends, parts, eps, min_pts, metric=0, cf_in=0):
     per-rank program, the exchange replaced by handing each rank the list of all contributions."""
     world = len(parts)
     gens = [_exact_slabs_steps(backends[r], parts[r], eps, min_pts, metric, cf_in, r, world) for r in range(world)]
+    msgs = [next(g)[0] for g in gens]
+    results = [None] * world
+    while any(r is None for r in results):
+        nxt = []
+        for r, g in enumerate(gens):
+            try:
+                nxt.append(g.send(list(msgs))[0])
+            except StopIteration as e:
+                results[r] = e.value
+                nxt.append(None)
+        msgs = nxt
+    return results
+
+
+# ---------------------------------------------------------------------------------------------------
+# sharded_pipeline: the block pipeline with EVERY stage sharded (include/vcp.h: vcp_blocks_plan_dev ...)
+# ---------------------------------------------------------------------------------------------------
+def _pipeline_steps(backend, d_motor, n, eps, min_pts, pts_in_cell, small_max, rank, world, device, labels, d_key=None,
+                    swap_xy=True):
+    """The per-rank program as a generator (like _exact_slabs_steps): yields what it contributes to each exchange and
+    is sent back every rank's contribution.
+
+    Every rank reads the whole cloud (device pointer d_motor, n points) but repeats only the streaming passes that decide
+    the partition (bounds, first block, block of every point: MainForm.getClusterFromMotor, FrmMain.cs:1214-1258); it
+    then builds, clusters (StartCode :2782-2794) and merges (CompleteWork3 :1442-1504) its own share of the blocks.
+    Exchanges: (1) nine words per rank -- cluster counts for the global renumbering (:1460-1504), who asks whom to zero a
+    last entry (the clusLen quirk :1461-1465 / :1485-1488 across a share boundary), op counters, sizes; (2) the global
+    noise pass (:1507-1516) as exact_slabs over the ranks' zero lists -- O(boundary); (3) one all-gather of the
+    (index, label) pairs, 8 bytes per point, after which every rank scatters the full label array."""
+    i64 = torch.int64
+    info = backend.blocks_plan(d_motor, n, eps, min_pts, pts_in_cell, small_max, d_key)
+    cuts = backend.blocks_plan_cuts(world)
+    sh = backend.blocks_build(cuts[rank], cuts[rank + 1])
+    m, n_loc = sh["m"], sh["n_loc"]
+    local = torch.empty(max(m, 1), dtype=torch.int32, device=device)  # (every position of the share is written)
+    evals = backend.blocks_cluster_dev(sh["block_lo"], sh["block_hi"], local.data_ptr()) if m > 0 else 0
+    st = backend.blocks_finish_local(local.data_ptr())
+    mine = torch.tensor([[st["clusters"], st["kept"], st["err"], st["req"], st["nonempty"], st["last_nonzero"], evals, m,
+                          n_loc]], dtype=i64, device=device)
+    allst = torch.cat((yield mine, True), dim=0).cpu().numpy().astype(np.int64)
+    if int(allst[:, 2].sum()) != 0:
+        raise IndexError("clusForMerge index -1 while demoting the first cluster (FrmMain.cs:1487)")
+    # a share whose first non-empty block demotes its first cluster zeroes the last entry of the nearest earlier share
+    # that has a non-empty block (the C# walks clusForMerge backwards, :1485-1488); none there: the C# throws
+    zero_me = False
+    for q in range(world):
+        if allst[q, 3]:
+            prev = [p for p in range(q) if allst[p, 4]]
+            if not prev:
+                raise IndexError("clusForMerge index -1 while demoting the first cluster (FrmMain.cs:1487)")
+            zero_me = zero_me or prev[-1] == rank
+    kept_all = allst[:, 1]
+    kept_off, kept_total = int(kept_all[:rank].sum()), int(kept_all.sum())
+    clusters_total = int(allst[:, 0].sum())
+    z = backend.blocks_finish_zero(zero_me)
+    zc = torch.empty((max(z, 1), 2), dtype=torch.float64, device=device)
+    backend.blocks_finish_zcoords(zc.data_ptr(), swap_xy)
+    # FrmMain.cs:1507-1516: ONE DBImproved over all noise with cf preset -- the zero lists of the shares, in rank order,
+    # are the C#'s zero list; exact_slabs gives every rank the labels of its own part of it
+    ex = yield from _exact_slabs_steps(backend, zc[:z], eps, min_pts, 0, kept_total, rank, world)
+    zlab = ex["labels"].to(torch.int32).contiguous()
+    pairs = torch.empty(max(n_loc, 1), dtype=i64, device=device)
+    if torch.device(device).type == "cuda":
+        torch.cuda.current_stream(torch.device(device)).synchronize()  # zlab came from torch's stream
+    backend.blocks_finish_pairs(kept_off, zlab.data_ptr() if z > 0 else None, pairs.data_ptr())
+    allp = yield pairs[:n_loc], [int(c) for c in allst[:, 8]]
+    if labels is None:
+        labels = torch.zeros(max(n, 1), dtype=torch.int32, device=device)
+    for q in range(world):
+        cnt = int(allst[q, 8])
+        if cnt:
+            pq = allp[q].contiguous()
+            backend.scatter_pairs(pq.data_ptr(), cnt, n, labels.data_ptr())
+    return dict(labels=labels[:n], rows=info["rows"], cols=info["cols"], nblocks=info["nblocks"],
+                block_range=(sh["block_lo"], sh["block_hi"]), m=int(allst[:, 7].sum()), m_local=m, kept=kept_total,
+                del_sum=clusters_total - kept_total, cluster_amount=ex["cf"],
+                evals=int(allst[:, 6].sum()) + ex["dist_evals"], noise_points=ex["n_total"],
+                noise_halo=ex["halo"], collective_bytes=8 * max(int(c) for c in allst[:, 8]))
+
+
+def sharded_pipeline(backend, d_motor, n, eps, min_pts, pts_in_cell, small_max=3, group=None, device="cuda",
+                     labels=None, d_key=None):
+    """The block-partitioned pipeline (= vcp_dbscan_blocks, bit for bit) with partition, per-block clustering AND merge
+    sharded over the ranks of `group`.  d_motor: device (or, for the CPU stand-in, host) address of the whole cloud
+    [n, 2] float64 on every rank.  Returns the dict of _pipeline_steps; every rank gets the full label array."""
+    rank, world = _world(group)
+    gen = _pipeline_steps(backend, d_motor, n, eps, min_pts, pts_in_cell, small_max, rank, world, device, labels, d_key)
+    try:
+        msg, fixed = next(gen)
+        while True:
+            msg, fixed = gen.send(gather_rows(msg, group, fixed))
+    except StopIteration as e:
+        return e.value
+
+
+def sharded_pipeline_local(backends, d_motor, n, eps, min_pts, pts_in_cell, small_max=3, device="cuda", d_key=None):
+    """sharded_pipeline with every rank simulated in this process (one backend / context per rank, e.g. several contexts
+    on one GPU): the same per-rank program, the exchange replaced by handing each rank the list of all contributions."""
+    world = len(backends)
+    gens = [_pipeline_steps(backends[r], d_motor, n, eps, min_pts, pts_in_cell, small_max, r, world, device, None, d_key)
+            for r in range(world)]
     msgs = [next(g)[0] for g in gens]
     results = [None] * world
     while any(r is None for r in results):

@@ -88,13 +88,14 @@ __device__ __forceinline__ bool within(const double* a, const double* b, double 
 template <int METRIC>
 __device__ __forceinline__ float value32(const float* a, const float* b) {
   const float dx = a[0] - b[0], dy = a[1] - b[1];
+  // (the sign bit is clear in every case, also for a NaN: the counting kernels compare bit patterns)
   if (METRIC == VCP_L1_2D) {
     return fabsf(dx) + fabsf(dy);
   } else if (METRIC == VCP_L2_2D) {
-    return dx * dx + dy * dy;
+    return fabsf(dx * dx + dy * dy);
   } else {
     const float dz = a[2] - b[2];
-    return dx * dx + dy * dy + dz * dz;
+    return fabsf(dx * dx + dy * dy + dz * dz);
   }
 }
 
@@ -238,10 +239,28 @@ __global__ __launch_bounds__(TPB) void k_moments(const double* __restrict__ c, i
   }
 }
 
+// Order in which the counting kernels walk the candidate rows: the row of the point's OWN cell first, then the rows that
+// share a face with it, then the corner rows.  A candidate of the own row is within eps far more often than one of a
+// neighbouring row (the L1 diamond covers about half of the own row's three cells and a twelfth of each neighbour row's), so
+// a point in a dense region reaches min_pts -- and stops -- after a fraction of the candidates the bottom-up order tested.
+template <int GD>
+struct RowOrder;
+template <>
+struct RowOrder<2> {  // (2-D: own row first was measured neutral for the count and +5 % for the union phase, whose first tree
+  static constexpr int at(int k) { return k; }  // links come from the recorded lists: the bottom-up order stays)
+};
+template <>
+struct RowOrder<3> {  // rows are indexed (dz + 1) * 3 + (dy + 1)
+  static constexpr int at(int k) {
+    constexpr int o[9] = {1, 3, 4, 5, 7, 0, 2, 6, 8};
+    return o[k];
+  }
+};
+
 // iterate the candidate rows of a cell neighbourhood: f(s, e) for the position range of each of the 3 (9)
 // x-rows, in increasing position order; f returns false to stop early.  All row bounds are fetched up front
 // (6 or 18 independent cellstart loads in flight) instead of two dependent loads per row.
-template <int GD, class F>
+template <int GD, bool OWN_FIRST = false, class F>
 __device__ __forceinline__ void for_rows(const int* cc, const GridP& g, const CellTab& ct, F&& f) {
   constexpr int NR = GD == 3 ? 9 : 3;
   const int x0 = max(cc[0] - 1, 0), x1 = min(cc[0] + 1, g.D[0] - 1);
@@ -252,12 +271,14 @@ __device__ __forceinline__ void for_rows(const int* cc, const GridP& g, const Ce
     const int z = GD == 3 ? cc[2] + (r / 3) - 1 : 0;
     const bool ok = y >= 0 && y < g.D[1] && (GD != 3 || (z >= 0 && z < g.D[2]));
     const uint32_t base = ok ? cell_id<GD>(g, 0, y, z) : 0u;
-    rs[r] = ok ? ct_start(ct, base + x0) : 0u;
-    re[r] = ok ? ct_start(ct, base + x1 + 1) : 0u;
+    rs[r] = re[r] = 0u;
+    if (ok) ct_range(ct, base + x0, base + x1 + 1, rs[r], re[r]);
   }
-  for (int r = 0; r < NR; r++)
+  for (int k = 0; k < NR; k++) {
+    const int r = OWN_FIRST ? RowOrder<GD>::at(k) : k;
     if (rs[r] < re[r])
       if (!f(rs[r], re[r])) return;
+  }
 }
 
 // the same bounds as plain arrays, for kernels that keep per-lane state across rows (a loop body that is not
@@ -272,8 +293,8 @@ __device__ __forceinline__ void row_bounds(const int* cc, const GridP& g, const 
     const int z = GD == 3 ? cc[2] + (r / 3) - 1 : 0;
     const bool ok = y >= 0 && y < g.D[1] && (GD != 3 || (z >= 0 && z < g.D[2]));
     const uint32_t base = ok ? cell_id<GD>(g, 0, y, z) : 0u;
-    rs[r] = ok ? ct_start(ct, base + x0) : 0u;
-    re[r] = ok ? ct_start(ct, base + x1 + 1) : 0u;
+    rs[r] = re[r] = 0u;
+    if (ok) ct_range(ct, base + x0, base + x1 + 1, rs[r], re[r]);
   }
 }
 
@@ -446,11 +467,13 @@ __global__ __launch_bounds__(TPB) void k_core(ExactSrc xs, GridP g, double thr, 
     load_pt32<GD>(sorted32, p, qf);
     cell_of32<GD>(qf, g, cc);
   }
-  constexpr int UNR = GD == 3 ? 4 : VCP_UNR2;  // binary32 candidates: half the registers per candidate in flight
+  constexpr int UNR = 4;  // hit nibbles (binary32 candidates: half the registers per candidate in flight)
+  const uint32_t scLO = sc.lo < 0.0f ? 0u : __float_as_uint(sc.lo) + 1u;  // integer form of the screen, see k_core_lds
+  const uint32_t scS = __float_as_uint(sc.hi) + 1u - scLO;
   const int32_t myg = (GROUPED && live) ? sgroup[p] : 0;
   int cnt = 0, nrec = 0;
   const int NB = no.NB;
-  if (live) for_rows<GD>(cc, g, ct, [&](uint32_t s, uint32_t e) {
+  if (live) for_rows<GD, true>(cc, g, ct, [&](uint32_t s, uint32_t e) {
     // batches of UNR candidates: UNR independent loads in flight per lane (the loop is latency bound), the
     // early exit is checked once per batch.  Candidates are screened on their binary32 copies (within_scr).
     for (uint32_t j = s; j < e; j += UNR) {
@@ -462,12 +485,33 @@ __global__ __launch_bounds__(TPB) void k_core(ExactSrc xs, GridP g, double thr, 
         load_pt32<GD>(sorted32, jj, r[u]);
         if (GROUPED) gj[u] = sgroup[jj];
       }
+      // the screen on bit patterns, as in k_core_lds: one nibble of provisional hits per trip, no compare / select pairs
+      uint32_t w[UNR], nib = 0;
 #pragma unroll
-      for (int u = 0; u < UNR; u++) {
-        bool ok = (j + u < e) && within_scr<GD, METRIC>(qf, r[u], sc, xs, (uint32_t)p, j + u, thr);
-        if (GROUPED) ok = ok && gj[u] == myg;
-        cnt += ok ? 1 : 0;
-        if (ok && nrec < NB && j + u != (uint32_t)p) lnb[(nrec++) * TPB + threadIdx.x] = j + u;
+      for (int u = UNR - 1; u >= 0; u--) {
+        w[u] = __float_as_uint(value32<METRIC>(qf, r[u])) - scLO;
+        nib = __builtin_amdgcn_alignbit(nib, w[u] - scS, 31);
+      }
+      nib &= 0xFu >> (4u - min(e - j, 4u));  // candidates past the row
+      if (GROUPED) {
+#pragma unroll
+        for (int u = 0; u < UNR; u++) nib &= gj[u] == myg ? 0xFu : ~(1u << u);
+      }
+      if (min(min(w[0], w[1]), min(w[2], w[3])) < scS) {  // rare: some candidate is undecided
+        double q[3];
+        load_exact<GD>(xs, (uint32_t)p, q);
+#pragma unroll
+        for (int u = 0; u < UNR; u++)
+          if (((nib >> u) & 1u) && w[u] < scS) {
+            double rr[3];
+            load_exact<GD>(xs, j + u, rr);
+            if (!within<METRIC>(q, rr, thr)) nib &= ~(1u << u);
+          }
+      }
+      cnt += __popc(nib);
+      for (uint32_t m = nib; m != 0u && nrec < NB; m &= m - 1u) {
+        const uint32_t jj = j + (uint32_t)(__ffs((int)m) - 1);
+        if (jj != (uint32_t)p) lnb[(nrec++) * TPB + threadIdx.x] = jj;
       }
       if (cnt >= min_pts) return false;
     }
@@ -493,7 +537,7 @@ __global__ __launch_bounds__(TPB) void k_core(ExactSrc xs, GridP g, double thr, 
     // union-find start: parent[p] = p for expanding points, NONE for all others, so that the component kernels
     // can tell "expanding, and in which tree" from ONE 4-byte load per candidate
     parent[p] = isE ? (uint32_t)p : NONE;
-    minord[p] = NONE;
+    if (isE) minord[p] = NONE;  // (read at roots only, and a root is an expanding point)
   }
   nbr_flush(no, lnb, lnb + no.NB * TPB, nrec, blk, p, live);
   wl_count(isE, isB, (uint32_t)blk, blkE, blkB);
@@ -654,6 +698,9 @@ __global__ __launch_bounds__(TPB) void k_core_lds(ExactSrc xs, GridP g, double t
   uint32_t rs[NR], re[NR];
   const bool fits = tile_bounds<GD>(t, live, cc, g, ct, rs, re);
   constexpr int UNR = 4;  // hit nibbles
+  // integer form of the screen (see the trip below): values are non-negative, so their bit patterns order like they do
+  const uint32_t scLO = sc.lo < 0.0f ? 0u : __float_as_uint(sc.lo) + 1u;  // bits below this: inside for sure
+  const uint32_t scS = __float_as_uint(sc.hi) + 1u - scLO;                 // bits - scLO below this: undecided
   int cnt = 0;
   // per row a bit mask of which of the lane's first 32 candidates were hits (two extra VALU operations per candidate;
   // writing positions to LDS as they were found cost seven, plus the LDS that held them: 0.2 ms on this VALU-bound
@@ -665,7 +712,8 @@ __global__ __launch_bounds__(TPB) void k_core_lds(ExactSrc xs, GridP g, double t
     tile_load<GD>(t, sorted32);
     if (live) {
 #pragma unroll
-      for (int r = 0; r < NR; r++) {
+      for (int k = 0; k < NR; k++) {
+        const int r = RowOrder<GD>::at(k);
         if (cnt >= min_pts || rs[r] >= re[r]) continue;
         const uint32_t lo = t.lo[r];
         const uint32_t e = re[r] - lo, a = rs[r] - lo;
@@ -676,22 +724,24 @@ __global__ __launch_bounds__(TPB) void k_core_lds(ExactSrc xs, GridP g, double t
           float c[UNR][3];
 #pragma unroll
           for (int u = 0; u < UNR; u++) t.get(r, j + u, c[u]);
-          uint32_t nib = 0, am = 0;
+          // The screen on the BIT PATTERNS of the (non-negative) values: w = bits - LO is negative for a value the screen
+          // accepts outright, w < S (unsigned) for one it cannot decide, and the top bit of w - S says "provisional hit";
+          // v_alignbit shifts that bit into the trip's nibble -- no compare / select pairs (each costs wait states on
+          // this part: the old form spent a quarter of the trip in s_nop).  A NaN (bits above +inf's) is simply outside,
+          // which is what the exact test would have answered.
+          uint32_t w[UNR], nib = 0;
 #pragma unroll
-          for (int u = 0; u < UNR; u++) {
-            const float v = value32<METRIC>(qf, c[u]);
-            nib |= (v > sc.hi) ? 0u : (1u << u);  // a NaN stays provisional ...
-            am |= (v <= sc.lo) ? 0u : (1u << u);  // ... and undecided
+          for (int u = UNR - 1; u >= 0; u--) {
+            w[u] = __float_as_uint(value32<METRIC>(qf, c[u])) - scLO;
+            nib = __builtin_amdgcn_alignbit(nib, w[u] - scS, 31);
           }
-          const uint32_t lim = e - j >= (uint32_t)UNR ? 0xFu : ((1u << (e - j)) - 1u);
-          nib &= lim;
-          am &= nib;
-          if (am != 0u) {
+          nib &= 0xFu >> (4u - min(e - j, 4u));  // candidates past the lane's range
+          if (min(min(w[0], w[1]), min(w[2], w[3])) < scS) {  // rare: some candidate (maybe one past the range) is undecided
             double q[3];
             load_exact<GD>(xs, (uint32_t)p, q);
 #pragma unroll
             for (int u = 0; u < UNR; u++)
-              if ((am >> u) & 1u) {
+              if (((nib >> u) & 1u) && w[u] < scS) {
                 double rr[3];
                 load_exact<GD>(xs, lo + j + u, rr);
                 if (!within<METRIC>(q, rr, thr)) nib &= ~(1u << u);
@@ -699,15 +749,17 @@ __global__ __launch_bounds__(TPB) void k_core_lds(ExactSrc xs, GridP g, double t
           }
           cnt += __popc(nib);
           const uint32_t sh = j - a;
-          hm[r] |= sh < 32u ? nib << sh : 0u;
-          ovf |= sh < 32u ? 0u : nib;
+          const uint32_t first32 = (uint32_t)((int32_t)(sh - 32u) >> 31);  // all ones while the masks still have room
+          hm[r] |= (nib << (sh & 31u)) & first32;
+          ovf |= nib & ~first32;
           if (cnt >= min_pts) break;
         }
       }
     }
   } else if (live) {
 #pragma unroll
-    for (int r = 0; r < NR; r++) {
+    for (int k = 0; k < NR; k++) {
+      const int r = RowOrder<GD>::at(k);
       if (cnt >= min_pts) continue;
       for (uint32_t j = rs[r]; j < re[r]; j += UNR) {
         float rr[UNR][3];
@@ -760,7 +812,7 @@ __global__ __launch_bounds__(TPB) void k_core_lds(ExactSrc xs, GridP g, double t
     // union-find start: parent[p] = p for expanding points, NONE for all others, so that the component kernels
     // can tell "expanding, and in which tree" from ONE 4-byte load per candidate
     parent[p] = isE ? (uint32_t)p : NONE;
-    minord[p] = NONE;
+    if (isE) minord[p] = NONE;  // (read at roots only, and a root is an expanding point)
   }
   nbr_flush_masks<GD, METRIC>(no, t.lout, hm, rs, re, rescan, nrec, thr, xs, blk, p, live);
   wl_count(isE, isB, (uint32_t)blk, blkE, blkB);

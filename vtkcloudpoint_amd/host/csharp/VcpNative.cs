@@ -128,6 +128,17 @@ namespace vtkPointCloud
             out int cluster_amount, out long dist_evals);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_blocks_share_plan(uint[] blockstart, long nblocks, int world, long[] cuts);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_selftest_horn(double[] sums, long nd, double[] V, int use_v, double[] R1, double[] T1);
+        // the block pipeline with every stage sharded (include/vcp.h): one context per GPU, each building, clustering and
+        // merging its own share of the blocks; the exchanges between the stages are the host's (nine words per rank, the
+        // noise pass through vcp_slab_*, the (index, label) pairs) -- vtkcloudpoint_amd/distributed.py is the reference driver
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_blocks_plan_dev(IntPtr ctx, IntPtr d_key_xy, IntPtr d_motor, long n, double eps, int min_pts, int pts_in_cell, int small_max, out int rows, out int cols, out long nblocks, out long nsuper);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_blocks_plan_cuts(IntPtr ctx, int world, long[] cuts);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_blocks_build_dev(IntPtr ctx, long super_lo, long super_hi, out int block_lo, out int block_hi, out long m_loc, out long n_loc);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_blocks_finish_local_dev(IntPtr ctx, IntPtr d_local, long[] info8);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_blocks_finish_zero_dev(IntPtr ctx, int zero_last, out long z_count);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_blocks_finish_zcoords_dev(IntPtr ctx, int swap_xy, IntPtr d_zcoords);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_blocks_finish_pairs_dev(IntPtr ctx, int kept_offset, IntPtr d_zlab, IntPtr d_pairs);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vcp_scatter_pairs_dev(IntPtr ctx, IntPtr d_pairs, long count, long n, IntPtr d_labels);
 
         // The device set of the multi-GPU calls: created on first use from Devices (default: device 0 only), replaced when
         // Devices changes, destroyed by Shutdown().  One vcp_multi serves one call at a time (the lock below).

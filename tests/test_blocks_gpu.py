@@ -177,3 +177,60 @@ def test_blocks_multi_from_one_process_equals_the_single_device_call(vcp_ctx, or
         mc.dbscan_blocks(np.zeros((0, 2)), 0.07, 7, 200, 3)
     assert e.value.code == -2
     mc.close()
+
+
+# ---- the sort-free partition (csrc/blockpart.hip): the paths the benchmark clouds do not reach -----------------------
+def _check(vcp_ctx, oracle, motor, eps, mp, pic, what):
+    motor = np.ascontiguousarray(motor, dtype=np.float64)
+    o = oracle.block_pipeline(motor, eps, mp, pic, 3)
+    g = vcp_ctx.dbscan_blocks(motor, eps, mp, pic, 3)
+    _same(g, o, what)
+    return o
+
+
+def test_select_needs_many_passes(vcp_ctx, oracle):
+    """Radix select of the first block when the first digit (exponent of d) does not isolate it: an outlier at the minimum
+    corner puts every d into one octave; thousands of points share one d exactly (ties go by index through the index
+    digits, more keys than the single-workgroup end of the selection takes)."""
+    rng = np.random.default_rng(11)
+    n = 300_000
+    # everybody at x = 5 + tiny lattice noise, y below x: d = x - x_Min is one of a few values; the corner point fixes x_Min, y_Min
+    motor = np.empty((n, 2))
+    motor[:, 0] = 5.0 + rng.integers(0, 3, n) * 2.0 ** -10
+    motor[:, 1] = rng.random(n) * 4.0
+    motor[0] = (0.0, 0.0)
+    for pic in (7, 2000, 150_000):
+        _check(vcp_ctx, oracle, motor, 0.01, 5, pic, "one octave, pic %d" % pic)
+    # far outlier: all d within a relative 1e-6 of each other
+    motor2 = rng.random((100_000, 2)) * 10.0
+    motor2[17] = (-1.0e7, -1.0e7)
+    _check(vcp_ctx, oracle, motor2, 0.05, 4, 50, "far outlier at the minimum corner")
+
+
+def test_large_blocks_ties_and_general_kernel(vcp_ctx, oracle):
+    """Blocks of 10^4..10^5 points: cut into sub-ranges of d; a sub-range that comes out large (thousands of equal d) and a
+    block whose points ALL share one d (ordered by index) take the general kernel."""
+    rng = np.random.default_rng(12)
+    bg = rng.random((20_000, 2)) * 100.0                       # sparse background: decides the block size (large blocks)
+    blob = 50.0 + rng.normal(0.0, 0.4, size=(150_000, 2))      # one heart of 150 k points inside a block or two
+    ties = np.column_stack([np.full(6_000, 70.0), 20.0 + rng.random(6_000) * 3.0])   # 6 k points with one d exactly
+    line = np.column_stack([np.full(4_000, 90.0), 10.0 + np.arange(4_000) * 1e-4])   # a block that holds nothing else
+    motor = np.concatenate([bg, blob, ties, line])
+    motor = motor[rng.permutation(len(motor))]
+    motor[0] = (0.0, 0.0)
+    o = _check(vcp_ctx, oracle, motor, 0.02, 6, 300, "hearts, ties, one-d block")
+    counts = np.bincount(o["block_of"][o["block_of"] >= 0])
+    assert counts.max() > 30_000 and (counts > 1024).sum() >= 3
+
+
+def test_millions_of_blocks(vcp_ctx, oracle):
+    """A tiny first block makes millions of (mostly empty) blocks: super-buckets of more than 512 blocks (the split pass does
+    not track the range of d per block there: large blocks go to the general kernel)."""
+    rng = np.random.default_rng(13)
+    n = 120_000
+    motor = rng.random((n, 2)) * 10.0
+    motor[:4] = np.array([[0.0, 0.0], [0.004, 0.001], [0.002, 0.004], [0.003, 0.003]])  # first block: 0.004 x 0.004
+    dense = 5.0 + rng.random((3_000, 2)) * 0.003   # 3 000 points inside ONE tiny block
+    motor = np.concatenate([motor, dense])
+    o = _check(vcp_ctx, oracle, motor, 0.05, 4, 4, "tiny first block")
+    assert o["rows"] * o["cols"] > 4_500_000

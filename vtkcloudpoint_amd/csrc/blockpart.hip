@@ -990,6 +990,7 @@ int vcp_blocks_plan(vcp_ctx* ctx, BlocksState* s, const double* d_key, const dou
                     bool want_cuts) {
   hipStream_t st = ctx->stream;
   const bool keyed = d_key != d_motor;
+  s->planned = false;  // (set again at the end: a plan that fails half way leaves nothing a build could use)
   s->built = false;
   s->d_key = d_key;
   s->d_motor = d_motor;

@@ -733,6 +733,8 @@ int vcp_blocks_share(vcp_ctx* ctx, int rank, int world, int32_t* block_lo, int32
   BlocksState* s = ctx->blocks;
   if (!s || !s->ready) return vcp_fail(ctx, VCP_ERR_ARG, "vcp_blocks_begin has not run");
   if (world < 1 || rank < 0 || rank >= world) return vcp_fail(ctx, VCP_ERR_ARG, "rank/world");
+  if (s->b_lo != 0 || s->b_hi != s->nblocks)
+    return vcp_fail(ctx, VCP_ERR_ARG, "this context holds a share of the blocks already (vcp_blocks_build_dev)");
   // contiguous block ranges balanced on the point count (vcp_blocks_share_plan, multi.hip: the same arithmetic for the
   // multi-process ranks and for the device threads of vcp_dbscan_blocks_multi)
   std::vector<int64_t> cuts((size_t)world + 1);

@@ -937,15 +937,18 @@ __global__ __launch_bounds__(TPB) void k_union_init_list(const uint8_t* __restri
 // (C4 cloud: the scan kernel drops from 265 to 109 us; L2_3D: union phase 1.27 -> 0.58 ms).  Letting EVERY expanding
 // point join along its list was measured too: the scan falls to 87 us but that round costs 500 us in 2-D (all trees of
 // a blob hooked at once).  The second pass flattens what the joins built.
-template <bool JOIN>
+// JOIN = 2 (grids with a point or more per cell, where whole regions are one component): EVERY expanding point joins
+// along its list, not only the roots -- on the sparse benchmark cloud that round costs more than it saves the edge scan
+// (0.5 ms against 0.02), at eps 0.7 (half of the background is core, one giant component) the edge scan falls from 8.7 ms.
+template <int JOIN>
 __global__ __launch_bounds__(TPB) void k_flatten0(uint32_t* __restrict__ parent, WorkList wlE,
                                                  const uint8_t* __restrict__ flags, NbrOut no) {
   const uint32_t p = wl_fetch(wlE);  // expanding points only (a quarter of the positions here)
   if (p == NONE) return;
   uint32_t r = (uint32_t)p, x = ld_parent_cached(parent, r);
-  if (x == r) {
+  if (x == r || JOIN == 2) {
     if (!JOIN) return;
-    uint32_t rp = p;
+    uint32_t rp = JOIN == 2 ? uf_root(parent, p) : p;
     const int nrec = flags[p] >> 4;
     const uint32_t* li = nbr_list(no, p);
     uint32_t s0 = NONE, s1 = NONE, s2 = NONE;  // words already known to be in my tree
@@ -1113,6 +1116,7 @@ __global__ __launch_bounds__(TPB) void k_union(ExactSrc xs, GridP g, double thr,
 
 // flatten + smallest list position per component; lanes of a wave that share a root (the common
 // case inside a blob: the wave covers neighbouring cells) combine before one atomicMin
+template <bool FILTER>
 __global__ __launch_bounds__(TPB) void k_flatten(uint32_t* __restrict__ parent, const uint32_t* __restrict__ sord,
                                                 uint32_t* __restrict__ minord, WorkList wlE) {
   const uint32_t p = wl_fetch(wlE);
@@ -1136,7 +1140,12 @@ __global__ __launch_bounds__(TPB) void k_flatten(uint32_t* __restrict__ parent, 
     uint32_t m = mine ? v : NONE;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, d, 64));
-    if (lane == leader) atomicMin(&minord[lr], m);
+    // FILTER (grids with a point or more per cell): read first -- in a cloud that is one large component every wave would
+    // otherwise queue on one word (156 k atomics on the same address took 1.5 ms at eps 0.7; a stale read only lets a
+    // needless atomic through).  On sparse grids the extra dependent load costs more than it saves (+0.03 ms at 10 M).
+    if (lane == leader &&
+        (!FILTER || m < __hip_atomic_load(&minord[lr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+      atomicMin(&minord[lr], m);
     todo &= ~__ballot(mine);
   }
 }
@@ -1894,12 +1903,15 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
   const bool pre = GD == 2 || no.NB > 0;  // with lists the forest costs no search, so it pays in 3-D too
   if (no.NB > 0) {
     hipLaunchKernelGGL(k_union_init_list, dim3(nbl), dim3(TPB), 0, st, flags, parent, no, wlE);
-    hipLaunchKernelGGL(k_flatten0<true>, dim3(nbl), dim3(TPB), 0, st, parent, wlE, flags, no);
-    hipLaunchKernelGGL(k_flatten0<false>, dim3(nbl), dim3(TPB), 0, st, parent, wlE, flags, no);
+    static const int join_all = getenv("VCP_JOIN_ALL") ? atoi(getenv("VCP_JOIN_ALL")) : -1;  // test switch
+    const bool all = join_all >= 0 ? join_all != 0 : (uint64_t)n >= (uint64_t)g.ncells;
+    if (all) hipLaunchKernelGGL(k_flatten0<2>, dim3(nbl), dim3(TPB), 0, st, parent, wlE, flags, no);
+    else hipLaunchKernelGGL(k_flatten0<1>, dim3(nbl), dim3(TPB), 0, st, parent, wlE, flags, no);
+    hipLaunchKernelGGL(k_flatten0<0>, dim3(nbl), dim3(TPB), 0, st, parent, wlE, flags, no);
   } else if (GD == 2) {
     hipLaunchKernelGGL((k_union_init<GD, METRIC, GROUPED>), dim3(nbl), dim3(TPB), 0, st, xs, g, thr, ct, sgroup,
                        flags, parent, wlE, sorted32, sc);
-    hipLaunchKernelGGL(k_flatten0<false>, dim3(nbl), dim3(TPB), 0, st, parent, wlE, flags, no);
+    hipLaunchKernelGGL(k_flatten0<0>, dim3(nbl), dim3(TPB), 0, st, parent, wlE, flags, no);
   }
   const bool dense = pre && (uint64_t)n > (uint64_t)DENSE_PER_CELL * g.ncells;
   if (dense) {
@@ -1915,7 +1927,10 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
     hipLaunchKernelGGL((k_union<GD, METRIC, GROUPED, false>), dim3(nbl), dim3(TPB), 0, st, xs, g, thr, ct, sgroup,
                        parent, wlE, sorted32, sc);
   vcp_phase(ctx, "flatten_number");
-  hipLaunchKernelGGL(k_flatten, dim3(nbl), dim3(TPB), 0, st, parent, sord, minord, wlE);
+  if ((uint64_t)n >= (uint64_t)g.ncells)
+    hipLaunchKernelGGL(k_flatten<true>, dim3(nbl), dim3(TPB), 0, st, parent, sord, minord, wlE);
+  else
+    hipLaunchKernelGGL(k_flatten<false>, dim3(nbl), dim3(TPB), 0, st, parent, sord, minord, wlE);
   if (!GROUPED && ext && ext->slab) {
     // staged call: hand the local components to the caller and keep the grid state for vcp_slab_finish
     vcp_phase(ctx, "slab_components");

@@ -100,9 +100,14 @@ inline int env_int(const char* name, int dflt, int lo, int hi) {
 }
 
 inline PartGeom part_geom(int64_t n, uint32_t ncells) {
-  static const int csh = env_int("VCP_CPB_LOG2", 14, 10, 14);
+  static const int csh_max = env_int("VCP_CPB_LOG2", 14, 10, 14);
   static const int target = env_int("VCP_PART_CHUNKS", 256, 64, 8192);  // long runs per (bucket, chunk) matter more
   PartGeom p;                                                           // than workgroups per CU (part_bench)
+  // cells per bucket: 2^14 on the sparse grids of this path (tens of cells per point); on a coarse grid (eps well above
+  // the point spacing: the 10 M-point cloud at eps 0.7 has 1 M cells) that would leave a few dozen buckets of 10^5 records
+  // for 256 CUs -- the fine pass took 5.0 ms there, 0.3 ms with 2^10 -- so: about 4096 records per bucket, 2^10 .. 2^14 cells
+  int csh = csh_max;
+  while (csh > 10 && ((uint64_t)ncells >> csh) * 4096ull < (uint64_t)n) csh--;
   p.csh = (uint32_t)csh;
   p.B = (uint32_t)((((uint64_t)ncells + 1) + ((1ull << p.csh) - 1)) >> p.csh);  // the table has ncells + 1 entries
   p.a = 0;

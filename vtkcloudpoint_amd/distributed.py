@@ -264,7 +264,7 @@ def _union_min(keys, reps):
     return u, fin
 
 
-def _exact_slabs_steps(backend, coords, eps, min_pts, metric, cf_in, rank, world):
+def _exact_slabs_steps(backend, coords, eps, min_pts, metric, cf_in, rank, world, lean=False):
     """The per-rank program of exact_slabs as a generator: it yields the tensor it contributes to each
     exchange step and is sent back the list of all ranks' tensors (see exact_slabs / exact_slabs_local)."""
     if not (eps >= 0.0) or eps == float("inf"):
@@ -273,7 +273,9 @@ def _exact_slabs_steps(backend, coords, eps, min_pts, metric, cf_in, rank, world
     dev = coords.device
     f64, i64 = torch.float64, torch.int64
     x = coords[:, 0]
-    if n and not bool(torch.isfinite(coords).all()):
+    # lean (the noise pass of sharded_pipeline): the caller vouches for finite coordinates and wants labels only -- no pass
+    # over the coordinates, no core / classed flags
+    if n and not lean and not bool(torch.isfinite(coords).all()):
         raise ValueError("exact_slabs needs finite coordinates")
 
     # 1. x-interval and size of every rank's part; global position of my first point
@@ -316,28 +318,35 @@ def _exact_slabs_steps(backend, coords, eps, min_pts, metric, cf_in, rank, world
     hx = h[:, 0]
     inner = (hx >= lo_me - m1) & (hx <= hi_me + m1)
     out = dict(n=n, halo=nh, gofs=gofs)
-    labels = torch.zeros(max(n + nh, 1), dtype=torch.int32, device=dev)
-    is_core = torch.zeros(max(n + nh, 1), dtype=torch.uint8, device=dev)
-    is_classed = torch.zeros(max(n + nh, 1), dtype=torch.uint8, device=dev)
+    labels = (torch.empty if lean and n else torch.zeros)(max(n + nh, 1), dtype=torch.int32, device=dev)
+    is_core = None if lean else torch.zeros(max(n + nh, 1), dtype=torch.uint8, device=dev)
+    is_classed = None if lean else torch.zeros(max(n + nh, 1), dtype=torch.uint8, device=dev)
     if n:
         nl = n + nh
         local = torch.cat([coords, h[:, :dim]], dim=0).contiguous() if nh else coords.contiguous()
-        ordv = torch.cat([torch.arange(gofs, gofs + n, dtype=i64, device=dev), h[:, dim].to(i64)]).to(torch.int32)
-        noexp = torch.cat([torch.zeros(n, dtype=torch.uint8, device=dev), (~inner).to(torch.uint8)])
+        ordv = torch.arange(gofs, gofs + n, dtype=torch.int32, device=dev)
+        noexp = None
+        if nh:
+            ordv = torch.cat([ordv, h[:, dim].to(torch.int32)])
+            noexp = torch.cat([torch.zeros(n, dtype=torch.uint8, device=dev), (~inner).to(torch.uint8)])
         rep = torch.empty(nl, dtype=torch.int32, device=dev)
 
         # 4. grid, core flags, local components (HIP: vcp_slab_begin).  The library runs on its own stream:
         #    what torch queued above must have landed first.
         if dev.type == "cuda":
             torch.cuda.current_stream(dev).synchronize()
-        backend.slab_begin(local.data_ptr(), nl, dim, metric, float(eps), int(min_pts), noexp.data_ptr(),
-                           ordv.data_ptr(), rep.data_ptr(), is_core.data_ptr())
+        backend.slab_begin(local.data_ptr(), nl, dim, metric, float(eps), int(min_pts),
+                           None if noexp is None else noexp.data_ptr(), ordv.data_ptr(), rep.data_ptr(),
+                           None if is_core is None else is_core.data_ptr())
         comps = np.asarray(backend.slab_comps(), dtype=np.uint32).astype(np.int64)  # ascending seeds
         # 5. (point, local seed) for every expanding point another rank also sees, or that I see of theirs
-        cand = torch.cat([sidx, n + torch.nonzero(inner).reshape(-1)])
-        r = rep[cand]
-        keep = r != -1
-        pairs = torch.stack([ordv[cand][keep].to(i64), r[keep].to(i64)], dim=1)
+        if nh or sidx.numel():
+            cand = torch.cat([sidx, n + torch.nonzero(inner).reshape(-1)])
+            r = rep[cand]
+            keep = r != -1
+            pairs = torch.stack([ordv[cand][keep].to(i64), r[keep].to(i64)], dim=1)
+        else:  # nobody else's interval comes near (a single rank): no boundary
+            pairs = torch.zeros((0, 2), dtype=i64, device=dev)
     else:
         comps = np.zeros(0, np.int64)
         pairs = torch.zeros((0, 2), dtype=i64, device=dev)
@@ -385,12 +394,14 @@ def _exact_slabs_steps(backend, coords, eps, min_pts, metric, cf_in, rank, world
         tab_seed = np.zeros(len(tab_gid), np.int64)
         tab_seed[map_k] = final
         twice = backend.slab_finish(comps.astype(np.uint32), map_k.astype(np.uint32), tab_gid.astype(np.int32),
-                                    tab_seed.astype(np.uint32), gofs, n, labels.data_ptr(), is_classed.data_ptr())
+                                    tab_seed.astype(np.uint32), gofs, n, labels.data_ptr(),
+                                    None if is_classed is None else is_classed.data_ptr())
     else:
         twice = 0
     # 9. iritatorNum of the monolithic call: n_total * (queried points + seeds + border points queried twice)
     alltw = torch.cat((yield torch.tensor([[twice]], dtype=i64, device=dev), True), dim=0).cpu().numpy().reshape(-1)
-    out.update(labels=labels[:n], is_core=is_core[:n], is_classed=is_classed[:n], cf=int(cf_in) + k_total,
+    out.update(labels=labels[:n], is_core=None if is_core is None else is_core[:n],
+               is_classed=None if is_classed is None else is_classed[:n], cf=int(cf_in) + k_total,
                dist_evals=n_total * (n_total + k_total + int(alltw.sum())), n_total=n_total,
                boundary_pairs=int(allpairs.shape[0]))
     return out
@@ -475,7 +486,7 @@ def _pipeline_steps(backend, d_motor, n, eps, min_pts, pts_in_cell, small_max, r
     backend.blocks_finish_zcoords(zc.data_ptr(), swap_xy)
     # FrmMain.cs:1507-1516: ONE DBImproved over all noise with cf preset -- the zero lists of the shares, in rank order,
     # are the C#'s zero list; exact_slabs gives every rank the labels of its own part of it
-    ex = yield from _exact_slabs_steps(backend, zc[:z], eps, min_pts, 0, kept_total, rank, world)
+    ex = yield from _exact_slabs_steps(backend, zc[:z], eps, min_pts, 0, kept_total, rank, world, lean=True)
     zlab = ex["labels"].to(torch.int32).contiguous()
     pairs = torch.empty(max(n_loc, 1), dtype=i64, device=device)
     if torch.device(device).type == "cuda":

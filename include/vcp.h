@@ -196,11 +196,15 @@ int vcp_blocks_finish_dev(vcp_ctx* ctx, const int32_t* d_local, int64_t evals_bl
  *             request (the demotion quirk of :1485-1488 reaches the last entry of an EARLIER share), the share has a
  *             non-empty block, its last entry still carries a label, m_loc, n_loc}
  *   -- exchange: kept offsets; whose last entry is zeroed (the nearest earlier share with a non-empty block) --
- *   zero      zero_last != 0: zero that entry; the zero list of the share (:1510-1515): *z_count points
- *   zcoords   their coordinates [z_count * 2] in zero-list order (swap_xy: as (y, x); shares are bands in y)
- *   -- the global noise pass over all shares' zero lists: vcp_slab_* (exact DBSCAN over several GPUs), cf preset --
- *   pairs     d_pairs [n_loc] = (original index << 32 | final label): kept clusters + kept_offset, noise points with
- *             d_zlab [z_count] (their labels from the noise pass), points in no block 0
+ *   zero      zero_last != 0: zero that entry; the zero list of the share (:1510-1515): *z_count points, of which
+ *             *active_count can be reached by the noise pass at all -- those within 2 eps of their block's boundary and
+ *             those that lost a label (csrc/blocks.hip: k_zero_flag); everybody else provably keeps 0
+ *   zcoords   the active points' coordinates [active_count * 2] in zero-list order (swap_xy: as (y, x); shares are bands
+ *             in y)
+ *   -- the global noise pass over all shares' active points: vcp_slab_* (exact DBSCAN over several GPUs), cf preset;
+ *      DBImproved.iritatorNum of the pass = Z x (Z + clusters + border points queried twice), Z = sum of z_count --
+ *   pairs     d_pairs [n_loc] = (original index << 32 | final label): kept clusters + kept_offset, active points with
+ *             d_zlab [active_count] (their labels from the noise pass), everybody else 0
  *   scatter   d_labels[index] = label for count pairs (any rank's), indices < n */
 int vcp_blocks_plan_dev(vcp_ctx* ctx, const double* d_key_xy, const double* d_motor, int64_t n, double eps, int min_pts,
                         int pts_in_cell, int small_max, int32_t* rows, int32_t* cols, int64_t* nblocks, int64_t* nsuper);
@@ -208,7 +212,7 @@ int vcp_blocks_plan_cuts(vcp_ctx* ctx, int world, int64_t* cuts);
 int vcp_blocks_build_dev(vcp_ctx* ctx, int64_t super_lo, int64_t super_hi, int32_t* block_lo, int32_t* block_hi,
                          int64_t* m_loc, int64_t* n_loc);
 int vcp_blocks_finish_local_dev(vcp_ctx* ctx, const int32_t* d_local, int64_t info[8]);
-int vcp_blocks_finish_zero_dev(vcp_ctx* ctx, int zero_last, int64_t* z_count);
+int vcp_blocks_finish_zero_dev(vcp_ctx* ctx, int zero_last, int64_t* z_count, int64_t* active_count);
 int vcp_blocks_finish_zcoords_dev(vcp_ctx* ctx, int swap_xy, double* d_zcoords);
 int vcp_blocks_finish_pairs_dev(vcp_ctx* ctx, int32_t kept_offset, const int32_t* d_zlab, int64_t* d_pairs);
 int vcp_scatter_pairs_dev(vcp_ctx* ctx, const int64_t* d_pairs, int64_t count, int64_t n, int32_t* d_labels);

@@ -464,10 +464,16 @@ class StagedPipeline(StagedSlab):
         np.add.at(blockstart, block_of[block_of >= 0].astype(np.int64) + 1, 1)
         blockstart = np.cumsum(blockstart)
         dropped = np.nonzero(block_of < 0)[0].astype(np.int64)
+        # the rectangles as FrmMain.cs:1262-1285 evaluates them (for the active set of the noise pass)
+        x_min, x_max = motor[:, 0].min(), motor[:, 0].max()
+        y_min, y_max = motor[:, 1].min(), motor[:, 1].max()
+        first = motor[bl[: int(blockstart[1])]]
+        geo = dict(x_min=x_min, x_max=x_max, y_min=y_min, y_max=y_max, cell_x=first[:, 0].max() - x_min,
+                   cell_y=first[:, 1].max() - y_min, rows=rows.value, cols=cols.value)
         # "super-bucket" S = block S; the last one (S = nblocks) holds the points in no block
         sbstart = np.concatenate([blockstart, [n]]).astype(np.int64)
         self.p = dict(motor=motor, n=n, eps=float(eps), min_pts=int(min_pts), small_max=int(small_max), bl=bl,
-                      blockstart=blockstart, nblocks=nblocks, m=m.value, dropped=dropped, sbstart=sbstart)
+                      blockstart=blockstart, nblocks=nblocks, m=m.value, dropped=dropped, sbstart=sbstart, geo=geo)
         return dict(rows=rows.value, cols=cols.value, nblocks=nblocks, nsuper=nblocks + 1)
 
     def blocks_plan_cuts(self, world):
@@ -544,7 +550,7 @@ class StagedPipeline(StagedSlab):
             last_block_end = e
         nonempty = last_block_end is not None
         last_nonzero = bool(nonempty and newlab[order[last_block_end - 1]] != 0)
-        p.update(newlab=newlab, order=order, last_pos=(int(order[last_block_end - 1]) if nonempty else -1))
+        p.update(newlab=newlab, order=order, last_pos=(int(order[last_block_end - 1]) if nonempty else -1), local=local)
         return dict(clusters=clusters, kept=kept, err=err, req=req, nonempty=int(nonempty),
                     last_nonzero=int(last_nonzero), m=m, n_loc=p["n_loc"])
 
@@ -553,8 +559,26 @@ class StagedPipeline(StagedSlab):
         if zero_last and p["last_pos"] >= 0:
             p["newlab"][p["last_pos"]] = 0
         inorder = p["newlab"][p["order"]] if p["m_loc"] else np.zeros(0, np.int32)
-        p["zpos"] = p["order"][inorder == 0]  # the zero list, in final order (FrmMain.cs:1510-1515)
-        return int(len(p["zpos"]))
+        zall = p["order"][inorder == 0]  # the zero list, in final order (FrmMain.cs:1510-1515)
+        # active = what the noise pass can reach (product: csrc/blocks.hip k_zero_flag): lost a label, or not more than
+        # 2 eps inside its rectangle
+        g, s0 = p["geo"], int(p["blockstart"][p["b_lo"]])
+        idx = p["bl"][s0 + zall]
+        xy = p["motor"][idx]
+        blk = np.searchsorted(p["blockstart"], s0 + zall, side="right") - 1
+        pr, q = blk // g["cols"], blk % g["cols"]
+        lox = g["x_min"] + q.astype(np.float64) * g["cell_x"]
+        hix = np.where(q == g["cols"] - 1, g["x_max"], g["x_min"] + (q + 1).astype(np.float64) * g["cell_x"])
+        loy = g["y_min"] + pr.astype(np.float64) * g["cell_y"]
+        hiy = np.where(pr == g["rows"] - 1, g["y_max"], g["y_min"] + (pr + 1).astype(np.float64) * g["cell_y"])
+        r2 = 2.0 * p["eps"] * (1.0 + 2.0 ** -40)
+        with np.errstate(invalid="ignore"):
+            interior = (xy[:, 0] - lox > r2) & (hix - xy[:, 0] > r2) & (xy[:, 1] - loy > r2) & (hiy - xy[:, 1] > r2)
+        act = (p["local"][zall] > 0) | ~interior
+        if not (p["eps"] >= 0.0):
+            act[:] = True
+        p["zpos"] = zall[act]
+        return int(len(zall)), int(len(p["zpos"]))
 
     def blocks_finish_zcoords(self, ptr, swap_xy=True):
         p = self.p

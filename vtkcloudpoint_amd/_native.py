@@ -374,9 +374,10 @@ class Context:
         return dict(zip(keys, (int(v) for v in info)))
 
     def blocks_finish_zero(self, zero_last):
-        z = C.c_int64(0)
-        self._chk(lib().vcp_blocks_finish_zero_dev(self._h, int(bool(zero_last)), C.byref(z)))
-        return z.value
+        """-> (points of the share's zero list, those of them the noise pass can reach: the ones it runs over)"""
+        z, a = C.c_int64(0), C.c_int64(0)
+        self._chk(lib().vcp_blocks_finish_zero_dev(self._h, int(bool(zero_last)), C.byref(z), C.byref(a)))
+        return z.value, a.value
 
     def blocks_finish_zcoords(self, d_zcoords, swap_xy=True):
         self._chk(lib().vcp_blocks_finish_zcoords_dev(self._h, int(bool(swap_xy)), _ptr(d_zcoords)))

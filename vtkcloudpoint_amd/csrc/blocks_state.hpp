@@ -40,7 +40,7 @@ struct BlocksState {
   // the finish stage's counters between its parts (blocks.hip: finish_local / finish_zero)
   bool f_by_sort = false;
   const int32_t* f_local = nullptr;
-  uint32_t f_totalC = 0, f_kept = 0, f_err = 0, f_req = 0, f_nonempty = 0, f_last_nonzero = 0, f_Z = 0;
+  uint32_t f_totalC = 0, f_kept = 0, f_err = 0, f_req = 0, f_nonempty = 0, f_last_nonzero = 0, f_Z = 0, f_A = 0;
   bool ready = false;
 };
 

@@ -264,7 +264,7 @@ def _union_min(keys, reps):
     return u, fin
 
 
-def _exact_slabs_steps(backend, coords, eps, min_pts, metric, cf_in, rank, world, lean=False):
+def _exact_slabs_steps(backend, coords, eps, min_pts, metric, cf_in, rank, world, lean=False, extra=0.0):
     """The per-rank program of exact_slabs as a generator: it yields the tensor it contributes to each
     exchange step and is sent back the list of all ranks' tensors (see exact_slabs / exact_slabs_local)."""
     if not (eps >= 0.0) or eps == float("inf"):
@@ -279,11 +279,13 @@ def _exact_slabs_steps(backend, coords, eps, min_pts, metric, cf_in, rank, world
         raise ValueError("exact_slabs needs finite coordinates")
 
     # 1. x-interval and size of every rank's part; global position of my first point
+    # (`extra`: one number of the caller's that rides along in this first exchange; all ranks' come back as out["extras"])
     if n:
-        info = torch.stack([x.min(), x.max(), torch.tensor(float(n), dtype=f64, device=dev)])
+        info = torch.stack([x.min(), x.max(), torch.tensor(float(n), dtype=f64, device=dev),
+                            torch.tensor(float(extra), dtype=f64, device=dev)])
     else:
-        info = torch.tensor([float("inf"), float("-inf"), 0.0], dtype=f64, device=dev)
-    allinfo = torch.stack((yield info.reshape(1, 3), True)).reshape(world, 3).cpu().numpy()
+        info = torch.tensor([float("inf"), float("-inf"), 0.0, float(extra)], dtype=f64, device=dev)
+    allinfo = torch.stack((yield info.reshape(1, 4), True)).reshape(world, 4).cpu().numpy()
     sizes = allinfo[:, 2].astype(np.int64)
     gofs = int(sizes[:rank].sum())
     n_total = int(sizes.sum())
@@ -402,7 +404,8 @@ def _exact_slabs_steps(backend, coords, eps, min_pts, metric, cf_in, rank, world
     alltw = torch.cat((yield torch.tensor([[twice]], dtype=i64, device=dev), True), dim=0).cpu().numpy().reshape(-1)
     out.update(labels=labels[:n], is_core=None if is_core is None else is_core[:n],
                is_classed=None if is_classed is None else is_classed[:n], cf=int(cf_in) + k_total,
-               dist_evals=n_total * (n_total + k_total + int(alltw.sum())), n_total=n_total,
+               dist_evals=n_total * (n_total + k_total + int(alltw.sum())), n_total=n_total, clusters=k_total,
+               twice=int(alltw.sum()), extras=allinfo[:, 3].copy(),
                boundary_pairs=int(allpairs.shape[0]))
     return out
 
@@ -481,12 +484,17 @@ def _pipeline_steps(backend, d_motor, n, eps, min_pts, pts_in_cell, small_max, r
     kept_all = allst[:, 1]
     kept_off, kept_total = int(kept_all[:rank].sum()), int(kept_all.sum())
     clusters_total = int(allst[:, 0].sum())
-    z = backend.blocks_finish_zero(zero_me)
+    z_all, z = backend.blocks_finish_zero(zero_me)  # the share's zero list, and the part of it the noise pass can reach
     zc = torch.empty((max(z, 1), 2), dtype=torch.float64, device=device)
     backend.blocks_finish_zcoords(zc.data_ptr(), swap_xy)
     # FrmMain.cs:1507-1516: ONE DBImproved over all noise with cf preset -- the zero lists of the shares, in rank order,
-    # are the C#'s zero list; exact_slabs gives every rank the labels of its own part of it
-    ex = yield from _exact_slabs_steps(backend, zc[:z], eps, min_pts, 0, kept_total, rank, world, lean=True)
+    # are the C#'s zero list; the pass runs over its ACTIVE points only (csrc/blocks.hip: k_zero_flag -- everybody else
+    # provably keeps 0, and the order among the active points is the zero list's); exact_slabs gives every rank the labels
+    # of its own part
+    ex = yield from _exact_slabs_steps(backend, zc[:z], eps, min_pts, 0, kept_total, rank, world, lean=True,
+                                       extra=float(z_all))
+    z_total = int(round(float(ex["extras"].sum())))
+    noise_evals = z_total * (z_total + ex["clusters"] + ex["twice"])  # iritatorNum of the pass over the whole zero list
     zlab = ex["labels"].to(torch.int32).contiguous()
     pairs = torch.empty(max(n_loc, 1), dtype=i64, device=device)
     if torch.device(device).type == "cuda":
@@ -503,7 +511,7 @@ def _pipeline_steps(backend, d_motor, n, eps, min_pts, pts_in_cell, small_max, r
     return dict(labels=labels[:n], rows=info["rows"], cols=info["cols"], nblocks=info["nblocks"],
                 block_range=(sh["block_lo"], sh["block_hi"]), m=int(allst[:, 7].sum()), m_local=m, kept=kept_total,
                 del_sum=clusters_total - kept_total, cluster_amount=ex["cf"],
-                evals=int(allst[:, 6].sum()) + ex["dist_evals"], noise_points=ex["n_total"],
+                evals=int(allst[:, 6].sum()) + noise_evals, noise_points=z_total, noise_active=ex["n_total"],
                 noise_halo=ex["halo"], collective_bytes=8 * max(int(c) for c in allst[:, 8]))
 
 

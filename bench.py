@@ -400,9 +400,10 @@ def main():
         if dist and world > 1:
             collectives.append({"op": "all_gather of 9 int64 per rank (cluster counts, quirk flags, op counters, sizes)",
                                 "backend": "nccl (RCCL)", "per_step": 1})
-            collectives.append({"op": "noise pass as exact_slabs over the ranks' zero lists: x-intervals, 2*eps halo "
-                                      "strips, boundary (point, seed) pairs, published ids, twice counters",
-                                "backend": "nccl (RCCL)", "per_step": 5})
+            collectives.append({"op": "all_gather (sizes, then data) of the active noise points' coordinates: 16 B per "
+                                      "point the global noise pass can reach (an eighth of the zero list); the pass itself "
+                                      "runs on every rank", "backend": "nccl (RCCL)", "per_step": 2,
+                                "active_noise_points": last.get("noise_active")})
             collectives.append({"op": "all_gather_into_tensor((index, label) int64 pairs, padded to the largest share)",
                                 "backend": "nccl (RCCL)", "bytes_sent_per_rank_per_step": last["collective_bytes"],
                                 "per_step": 1})
@@ -537,9 +538,9 @@ def main():
                       "metric %s, eps %g, minPts %d" % (n, n // 50_000, args.metric, eps, min_pts),
             "blocks": "C4: ONE %d-pt cloud, block-partitioned DBImproved pipeline at the reference defaults (eps %g, "
                       "minPts %d, %d points per block) on %d GPU(s): every rank repeats the streaming passes that decide "
-                      "the partition and builds, clusters and merges its own share of the blocks; noise pass as exact "
-                      "slabs; RCCL all-gather of (index, label) pairs inside the timed region; every rank ends with the "
-                      "full label array" % (n, BLOCK_DEFAULTS["eps"], BLOCK_DEFAULTS["min_pts"],
+                      "the partition and builds, clusters and merges its own share of the blocks; the noise pass over "
+                      "its gathered active points on every rank; RCCL all-gather of (index, label) pairs inside the timed "
+                      "region; every rank ends with the full label array" % (n, BLOCK_DEFAULTS["eps"], BLOCK_DEFAULTS["min_pts"],
                                             BLOCK_DEFAULTS["pts_in_cell"], world),
             "exact": "C4 family: %d-pt x-slab per GPU of one cloud, exact monolithic DBImproved.dbscan result (2*eps "
                      "halo + boundary union over RCCL, labels stay on the owning rank), metric %s, eps %g, minPts %d"

@@ -607,6 +607,12 @@ class StagedPipeline(StagedSlab):
         out = np.ctypeslib.as_array(C.cast(pairs_ptr, C.POINTER(C.c_int64)), shape=(max(n_loc, 1),))
         out[:n_loc] = (idx << 32) | (lab & 0xFFFFFFFF)
 
+    def dbscan_dev(self, cptr, n, dim, eps, min_pts, metric=L1_2D, cf_in=0, d_in_classed=None, lptr=None, *a):
+        coords = np.ctypeslib.as_array(C.cast(cptr, C.POINTER(C.c_double)), shape=(n, dim))
+        r = dbscan(coords, eps, min_pts, metric, cf_in)
+        np.ctypeslib.as_array(C.cast(lptr, C.POINTER(C.c_int32)), shape=(n,))[:] = r["labels"]
+        return r["cf"], r["evals"]
+
     def scatter_pairs(self, pairs_ptr, count, n, labels_ptr):
         pr = np.ctypeslib.as_array(C.cast(pairs_ptr, C.POINTER(C.c_int64)), shape=(count,))
         labels = np.ctypeslib.as_array(C.cast(labels_ptr, C.POINTER(C.c_int32)), shape=(n,))

@@ -30,13 +30,15 @@ def main():
         motor = (rng.integers(0, 40, size=(n, 2)).astype(np.float64) * 0.25 if trial % 2 else rng.random((n, 2)) * 10)
         cases.append((np.ascontiguousarray(motor), float(rng.choice([0.25, 0.5, 0.75])), int(rng.integers(1, 6)),
                       int(rng.integers(3, 60))))
-    for motor, eps, mp, pic in cases:
+    for case_no, (motor, eps, mp, pic) in enumerate(cases):
+        noise = ("gather", "slabs")[case_no % 2]  # the noise pass: active points gathered, or exact slabs over the shares
         try:
             ref = O.block_pipeline(motor, eps, mp, pic, 3)
         except O.OracleError:
             ref = None
         try:
-            r = D.sharded_pipeline(O.StagedPipeline(), motor.ctypes.data, len(motor), eps, mp, pic, 3, device="cpu")
+            r = D.sharded_pipeline(O.StagedPipeline(), motor.ctypes.data, len(motor), eps, mp, pic, 3, device="cpu",
+                                   noise=noise)
         except IndexError:
             r = None
         if ref is None or r is None:

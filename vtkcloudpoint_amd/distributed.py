@@ -448,7 +448,7 @@ def exact_slabs_local(backends, parts, eps, min_pts, metric=0, cf_in=0):
 # sharded_pipeline: the block pipeline with EVERY stage sharded (include/vcp.h: vcp_blocks_plan_dev ...)
 # ---------------------------------------------------------------------------------------------------
 def _pipeline_steps(backend, d_motor, n, eps, min_pts, pts_in_cell, small_max, rank, world, device, labels, d_key=None,
-                    swap_xy=True):
+                    noise="gather"):
     """The per-rank program as a generator (like _exact_slabs_steps): yields what it contributes to each exchange and
     is sent back every rank's contribution.
 
@@ -457,8 +457,12 @@ def _pipeline_steps(backend, d_motor, n, eps, min_pts, pts_in_cell, small_max, r
     then builds, clusters (StartCode :2782-2794) and merges (CompleteWork3 :1442-1504) its own share of the blocks.
     Exchanges: (1) nine words per rank -- cluster counts for the global renumbering (:1460-1504), who asks whom to zero a
     last entry (the clusLen quirk :1461-1465 / :1485-1488 across a share boundary), op counters, sizes; (2) the global
-    noise pass (:1507-1516) as exact_slabs over the ranks' zero lists -- O(boundary); (3) one all-gather of the
-    (index, label) pairs, 8 bytes per point, after which every rank scatters the full label array."""
+    noise pass (:1507-1516) over the ACTIVE points of the ranks' zero lists (the eighth of the noise a cluster of that pass
+    can reach, csrc/blocks.hip: k_zero_flag) -- noise="gather": ONE all-gather of their coordinates (16 bytes per active
+    point) and the pass itself on every rank (0.3 ms at 10 M points: cheaper than any exchange pattern); noise="slabs":
+    exact_slabs over the shares (bands in y), O(boundary), for clouds whose active set is too large to repeat;
+    (3) one all-gather of the (index, label) pairs, 8 bytes per point, after which every rank scatters the full label
+    array."""
     i64 = torch.int64
     info = backend.blocks_plan(d_motor, n, eps, min_pts, pts_in_cell, small_max, d_key)
     cuts = backend.blocks_plan_cuts(world)
@@ -485,16 +489,42 @@ def _pipeline_steps(backend, d_motor, n, eps, min_pts, pts_in_cell, small_max, r
     kept_off, kept_total = int(kept_all[:rank].sum()), int(kept_all.sum())
     clusters_total = int(allst[:, 0].sum())
     z_all, z = backend.blocks_finish_zero(zero_me)  # the share's zero list, and the part of it the noise pass can reach
-    zc = torch.empty((max(z, 1), 2), dtype=torch.float64, device=device)
-    backend.blocks_finish_zcoords(zc.data_ptr(), swap_xy)
+    if noise == "gather":
+        # header row (zero-list size, active points) + the active points' coordinates, every rank's to every rank
+        zc = torch.empty((z + 1, 2), dtype=torch.float64, device=device)
+        backend.blocks_finish_zcoords(zc[1:].data_ptr(), False)
+        zc[0, 0] = float(z_all)
+        zc[0, 1] = float(z)
+        allz = yield zc, False
+        z_total = int(round(sum(float(t[0, 0]) for t in allz)))
+        a_off = sum(int(t.shape[0]) - 1 for t in allz[:rank])
+        coords = torch.cat([t[1:] for t in allz], dim=0).contiguous() if world > 1 else zc[1:]
+        a_total = int(coords.shape[0])
+        zlab_all = torch.empty(max(a_total, 1), dtype=torch.int32, device=device)
+        cf, ev = kept_total, 0
+        if a_total:
+            if torch.device(device).type == "cuda":
+                torch.cuda.current_stream(torch.device(device)).synchronize()  # coords came from torch's stream
+            cf, ev = backend.dbscan_dev(coords.data_ptr(), a_total, 2, eps, min_pts, 0, kept_total, None,
+                                        zlab_all.data_ptr())
+        k = cf - kept_total
+        twice = ev // a_total - a_total - k if a_total else 0  # engine: A x (A + K + twice)
+        ex = dict(labels=zlab_all[a_off: a_off + z], cf=cf, n_total=a_total, halo=0)
+        noise_evals = z_total * (z_total + k + twice)
+    else:
+        ex = None
+    zc = torch.empty((max(z, 1), 2), dtype=torch.float64, device=device) if ex is None else None
+    if ex is None:
+        backend.blocks_finish_zcoords(zc.data_ptr(), True)  # as (y, x): the shares are bands in y
     # FrmMain.cs:1507-1516: ONE DBImproved over all noise with cf preset -- the zero lists of the shares, in rank order,
     # are the C#'s zero list; the pass runs over its ACTIVE points only (csrc/blocks.hip: k_zero_flag -- everybody else
     # provably keeps 0, and the order among the active points is the zero list's); exact_slabs gives every rank the labels
     # of its own part
-    ex = yield from _exact_slabs_steps(backend, zc[:z], eps, min_pts, 0, kept_total, rank, world, lean=True,
-                                       extra=float(z_all))
-    z_total = int(round(float(ex["extras"].sum())))
-    noise_evals = z_total * (z_total + ex["clusters"] + ex["twice"])  # iritatorNum of the pass over the whole zero list
+    if ex is None:
+        ex = yield from _exact_slabs_steps(backend, zc[:z], eps, min_pts, 0, kept_total, rank, world, lean=True,
+                                           extra=float(z_all))
+        z_total = int(round(float(ex["extras"].sum())))
+        noise_evals = z_total * (z_total + ex["clusters"] + ex["twice"])  # iritatorNum of the pass over the whole zero list
     zlab = ex["labels"].to(torch.int32).contiguous()
     pairs = torch.empty(max(n_loc, 1), dtype=i64, device=device)
     if torch.device(device).type == "cuda":
@@ -516,12 +546,13 @@ def _pipeline_steps(backend, d_motor, n, eps, min_pts, pts_in_cell, small_max, r
 
 
 def sharded_pipeline(backend, d_motor, n, eps, min_pts, pts_in_cell, small_max=3, group=None, device="cuda",
-                     labels=None, d_key=None):
+                     labels=None, d_key=None, noise="gather"):
     """The block-partitioned pipeline (= vcp_dbscan_blocks, bit for bit) with partition, per-block clustering AND merge
     sharded over the ranks of `group`.  d_motor: device (or, for the CPU stand-in, host) address of the whole cloud
     [n, 2] float64 on every rank.  Returns the dict of _pipeline_steps; every rank gets the full label array."""
     rank, world = _world(group)
-    gen = _pipeline_steps(backend, d_motor, n, eps, min_pts, pts_in_cell, small_max, rank, world, device, labels, d_key)
+    gen = _pipeline_steps(backend, d_motor, n, eps, min_pts, pts_in_cell, small_max, rank, world, device, labels, d_key,
+                          noise)
     try:
         msg, fixed = next(gen)
         while True:
@@ -530,12 +561,13 @@ def sharded_pipeline(backend, d_motor, n, eps, min_pts, pts_in_cell, small_max=3
         return e.value
 
 
-def sharded_pipeline_local(backends, d_motor, n, eps, min_pts, pts_in_cell, small_max=3, device="cuda", d_key=None):
+def sharded_pipeline_local(backends, d_motor, n, eps, min_pts, pts_in_cell, small_max=3, device="cuda", d_key=None,
+                           noise="gather"):
     """sharded_pipeline with every rank simulated in this process (one backend / context per rank, e.g. several contexts
     on one GPU): the same per-rank program, the exchange replaced by handing each rank the list of all contributions."""
     world = len(backends)
-    gens = [_pipeline_steps(backends[r], d_motor, n, eps, min_pts, pts_in_cell, small_max, r, world, device, None, d_key)
-            for r in range(world)]
+    gens = [_pipeline_steps(backends[r], d_motor, n, eps, min_pts, pts_in_cell, small_max, r, world, device, None, d_key,
+                            noise) for r in range(world)]
     msgs = [next(g)[0] for g in gens]
     results = [None] * world
     while any(r is None for r in results):

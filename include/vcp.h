@@ -222,10 +222,12 @@ int vcp_scatter_pairs_dev(vcp_ctx* ctx, const int64_t* d_pairs, int64_t count, i
  * FrmMain.cs:1356-1359) and merges on the UI thread (CompleteWork3, :1442-1520).  vcp_multi is the drop-in form of
  * that for a host that owns several GPUs: one vcp_ctx per listed HIP device (a device id may repeat: several contexts
  * on one GPU), driven by one host thread each.  vcp_dbscan_blocks_multi = vcp_dbscan_blocks_keyed (key_xy may be NULL)
- * with the per-block DBImproved step sharded over the devices by contiguous block ranges balanced on point count
- * (vcp_blocks_share_plan); the block-major label slices travel to device 0 as peer copies over xGMI, device 0 runs
- * CompleteWork3.  Results are identical to the one-device call, bit for bit.  (The multi-PROCESS form -- one rank per
- * GPU, ONE RCCL all-gather -- is vtkcloudpoint_amd/distributed.py: sharded_blocks, over the staged entry points.) */
+ * with every stage sharded (round 3): each device repeats the streaming passes that decide the partition, then builds,
+ * clusters and merges its own share of the blocks (the vcp_blocks_plan_dev ... stages below); the shares' counters meet
+ * in this process's memory, the active points of the zero lists travel to device 0 as peer copies over xGMI, device 0
+ * runs the global noise pass over them and assembles the label array from the devices' (index, label) pairs.  Results
+ * are identical to the one-device call, bit for bit.  (The multi-PROCESS form -- one rank per GPU, RCCL all-gathers -- is
+ * vtkcloudpoint_amd/distributed.py: sharded_pipeline, over the same stages.) */
 typedef struct vcp_multi vcp_multi;
 int vcp_create_multi(const int* device_ids, int n, vcp_multi** out);
 void vcp_destroy_multi(vcp_multi* m);

@@ -176,6 +176,25 @@ def test_blocks_multi_from_one_process_equals_the_single_device_call(vcp_ctx, or
     with pytest.raises(N.VcpError) as e:
         mc.dbscan_blocks(np.zeros((0, 2)), 0.07, 7, 200, 3)
     assert e.value.code == -2
+    # small lattice clouds: demotions, the clusLen quirk across the devices' shares, the inputs on which the C# throws
+    rng = np.random.default_rng(5)
+    n_err = n_del = 0
+    for trial in range(80):
+        n = int(rng.integers(5, 400))
+        m2 = (rng.integers(0, 40, size=(n, 2)).astype(np.float64) * 0.25 if trial % 2 else rng.random((n, 2)) * 10)
+        eps, mp, pic = float(rng.choice([0.25, 0.5, 0.75])), int(rng.integers(1, 6)), int(rng.integers(3, 60))
+        try:
+            ob = oracle.block_pipeline(m2, eps, mp, pic, 3)
+        except oracle.OracleError as oe:
+            n_err += 1
+            with pytest.raises(N.VcpError) as ge:
+                mc.dbscan_blocks(m2, eps, mp, pic, 3)
+            assert ge.value.code == oe.code, "trial %d" % trial
+            continue
+        gm = mc.dbscan_blocks(m2, eps, mp, pic, 3)
+        _same(gm, ob, "multi trial %d" % trial)
+        n_del += ob["del_sum"] > 0
+    assert (n_err > 0 and n_del > 0) or len(devices) == 1
     mc.close()
 
 

@@ -933,6 +933,16 @@ int vcp_blocks_finish_zcoords_dev(vcp_ctx* ctx, int swap_xy, double* d_zcoords) 
   return VCP_OK;
 }
 
+// for multi.hip (several devices from one process): the zero-list stage with the share's part of clusForMerge --
+// d_merge_order [m_loc]: the non-zero entries in final order, then the share's zero list
+int vcp_blocks_finish_zcoords_order(vcp_ctx* ctx, double* d_zcoords, int64_t* d_merge_order) {
+  BlocksState* s = ctx->blocks;
+  if (!s || !s->ready || !s->f_local) return vcp_fail(ctx, VCP_ERR_ARG, "vcp_blocks_finish_zero_dev has not run");
+  VCP_TRY(finish_zcoords(ctx, d_zcoords, d_merge_order, 0));
+  VCP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VCP_OK;
+}
+
 int vcp_blocks_finish_pairs_dev(vcp_ctx* ctx, int32_t kept_offset, const int32_t* d_zlab, int64_t* d_pairs) {
   if (!ctx) return VCP_ERR_ARG;
   VCP_TRY(vcp_bind(ctx));

@@ -60,3 +60,6 @@ int vcp_blocks_partition(vcp_ctx* ctx, BlocksState* s, const double* d_key, cons
 int vcp_blocks_plan(vcp_ctx* ctx, BlocksState* s, const double* d_key, const double* d_motor, int64_t n, int pts_in_cell,
                     bool want_cuts);
 int vcp_blocks_build(vcp_ctx* ctx, BlocksState* s, uint32_t S_lo, uint32_t S_hi, uint32_t off0, int64_t n_loc);
+
+// internal (multi.hip): vcp_blocks_finish_zcoords_dev that also writes the share's part of the merge order
+extern "C" int vcp_blocks_finish_zcoords_order(vcp_ctx* ctx, double* d_zcoords, int64_t* d_merge_order);

@@ -92,3 +92,22 @@ def test_4m_shares_equal_the_single_device_call(ranks, vcp_ctx):
         assert np.array_equal(r["labels"].cpu().numpy(), ref["labels"]), "rank %d" % q
         for k in ("rows", "cols", "kept", "del_sum", "cluster_amount", "evals"):
             assert r[k] == ref[k], (q, k, r[k], ref[k])
+
+
+@pytest.mark.parametrize("noise", ["gather", "slabs"])
+def test_keyed_partition_shares(ranks, vcp_ctx, noise):
+    """getClusterFromList (partition on X, Y; clustering on motor): the block geometry says nothing about motor distances,
+    so every zero-list point is active in the noise pass."""
+    d = synth.config_cloud(150_000, seed=21)
+    motor = np.ascontiguousarray(d["motor"])
+    key = np.ascontiguousarray(d["xyz"][:, :2])
+    ref = vcp_ctx.dbscan_blocks(motor, 0.07, 7, 200, 3, key_xy=key)
+    dm, dk = torch.from_numpy(motor).cuda(), torch.from_numpy(key).cuda()
+    torch.cuda.synchronize()
+    res = D.sharded_pipeline_local(ranks[:3], dm.data_ptr(), len(motor), 0.07, 7, 200, 3, device="cuda", d_key=dk.data_ptr(),
+                                   noise=noise)
+    for q, r in enumerate(res):
+        assert np.array_equal(r["labels"].cpu().numpy(), ref["labels"]), "rank %d" % q
+        for k in ("rows", "cols", "kept", "del_sum", "cluster_amount", "evals"):
+            assert r[k] == ref[k], (q, k, r[k], ref[k])
+        assert r["noise_active"] == r["noise_points"]

@@ -18,7 +18,7 @@ d = torch.from_numpy(cloud["motor"]).cuda()
 local = torch.zeros(n, dtype=torch.int32, device="cuda")
 labels = torch.zeros(n, dtype=torch.int32, device="cuda")
 torch.cuda.synchronize()
-for it in range(4):
+for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 4):
     t0 = time.perf_counter()
     info = ctx.blocks_begin(None, 0.07, 7, 200, 3, device_ptr=d.data_ptr(), n=n)
     t1 = time.perf_counter()

@@ -410,7 +410,12 @@ __device__ __forceinline__ int find_axis(double v, double vmin, double vmax, dou
   // a guess (the window below decides with the C#'s own expressions); the division only where 1 / cellw overflows
   const double g = isfinite(inv_cellw) ? (v - vmin) * inv_cellw : (v - vmin) / cellw;
   const long long q0 = isfinite(g) ? (long long)floor(g) : 0;
-  for (long long q = q0 - 2; q <= q0 + 2; q++) {
+  // the intervals (lo, hi] are disjoint (hi(q) and lo(q + 1) are the same expression), so the order of the tests is free:
+  // the guess first -- it is right for all but the points within a rounding of an edge
+  const long long offs[5] = {0, -1, 1, -2, 2};
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    const long long q = q0 + offs[k];
     if (q < 0 || q >= cnt) continue;
     const double lo = vmin + (double)(int)q * cellw;
     const double hi = (q == cnt - 1) ? vmax : vmin + (double)((int)q + 1) * cellw;

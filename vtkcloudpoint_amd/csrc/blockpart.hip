@@ -754,14 +754,14 @@ __device__ __forceinline__ SbMap sb_map(uint32_t m, uint32_t sbmax, unsigned lon
 // BIG = true: workgroups of 1024 walk the general kernel's list: any size, ranks and the grouped keys through global
 // memory (L2: a run is contiguous); also copies the indices of the points in no block.
 template <bool BIG, bool LIST>
-__global__ __launch_bounds__(BIG ? 1024 : 256) void k_blk_sort(const Rec32* __restrict__ rec2, const Rec32* __restrict__ rec,
+__global__ __launch_bounds__(BIG ? 1024 : 128) void k_blk_sort(const Rec32* __restrict__ rec2, const Rec32* __restrict__ rec,
                                                                const uint32_t* __restrict__ blockstart, uint32_t nblocks,
                                                                const Desc* __restrict__ list, SelState* __restrict__ st,
                                                                Desc* __restrict__ fall, uint32_t* __restrict__ gcnt,
                                                                KeyPart* __restrict__ stage_g, uint32_t* __restrict__ rk_g,
                                                                double* __restrict__ motor_bm, uint32_t* __restrict__ bl,
                                                                uint32_t* __restrict__ blk_t, uint32_t b_lo, int has_dropped) {
-  constexpr int NT = BIG ? 1024 : 256;
+  constexpr int NT = BIG ? 1024 : 128;
   constexpr uint32_t SBMAX = BIG ? 8192u : 512u;
   constexpr uint32_t PER = SBMAX / NT;
   constexpr int RPT = BIG ? 1 : (int)(VCP_BIG_BLOCK / NT);  // records per thread kept in registers (small runs)
@@ -1165,7 +1165,7 @@ int vcp_blocks_build(vcp_ctx* ctx, BlocksState* s, uint32_t S_lo, uint32_t S_hi,
                             s->rank.as<uint32_t>(), s->motor_bm.as<double>(), s->bl.as<uint32_t>(), s->blk_t.as<uint32_t>(), \
                             b_lo, has_dropped ? 1 : 0
     if (s->b_hi > s->b_lo)
-      hipLaunchKernelGGL((k_blk_sort<false, false>), dim3(nbl), dim3(256), 0, st, VCP_SORT_ARGS(nullptr));
+      hipLaunchKernelGGL((k_blk_sort<false, false>), dim3(nbl), dim3(128), 0, st, VCP_SORT_ARGS(nullptr));
     const unsigned gsl = (unsigned)std::min<size_t>(2048, nbig_cap + nl / SLICE);
     hipLaunchKernelGGL(k_big_count, dim3(gsl), dim3(PT), 0, st, rec2, s->binfo.as<BigInfo>(), s->slicelist.as<uint2>(), d_sel,
                        gcnt);
@@ -1173,7 +1173,7 @@ int vcp_blocks_build(vcp_ctx* ctx, BlocksState* s, uint32_t S_lo, uint32_t S_hi,
                        d_sel, gcnt, vlist);
     hipLaunchKernelGGL(k_big_move, dim3(gsl), dim3(PT), 0, st, rec2, rec, s->binfo.as<BigInfo>(), s->slicelist.as<uint2>(),
                        d_sel, gcnt);
-    hipLaunchKernelGGL((k_blk_sort<false, true>), dim3((unsigned)std::min<size_t>(8192, nvirt_cap)), dim3(256), 0, st,
+    hipLaunchKernelGGL((k_blk_sort<false, true>), dim3((unsigned)std::min<size_t>(8192, nvirt_cap)), dim3(128), 0, st,
                        VCP_SORT_ARGS(vlist));
     hipLaunchKernelGGL((k_blk_sort<true, true>), dim3(256), dim3(1024), 0, st, VCP_SORT_ARGS(fall));
 #undef VCP_SORT_ARGS

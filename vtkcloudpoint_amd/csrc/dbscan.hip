@@ -1290,13 +1290,26 @@ __global__ __launch_bounds__(TPB) void k_border_list(const int32_t* __restrict__
       mx = max(mx, x + 1u);
       mnk = min(mnk, x);
     }
-    if (mx != 0 && sord[p] < clseed[mnk]) {  // nobody is classed on entry in these calls
-      twice = 1;
-      if (GROUPED) atomicAdd(&group_twice[sgroup[p]], 1u);
-    }
+    if (mx != 0 && sord[p] < clseed[mnk]) twice = 1;  // nobody is classed on entry in these calls
     labk[p] = (mx << 2) | ((fl & F_CORE) ? 1u : 0u) | ((fl & F_CLASSED) ? 2u : 0u);
   }
-  if (!GROUPED) twice_add(twice, counters);
+  if (GROUPED) {
+    // one add per group the wave's counted points fall into (the lanes of a wave are neighbours in cell order: one to three
+    // blocks) instead of one per point -- global atomics execute at the memory side here: a million of them on 27 k
+    // counters were 60 of this kernel's 96 us
+    const int32_t g = twice ? sgroup[p] : -1;
+    unsigned long long todo = __ballot(twice != 0);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int32_t gl = __shfl(g, leader, 64);
+      const unsigned long long same = __ballot(twice && g == gl);
+      if (lane == leader) atomicAdd(&group_twice[gl], (uint32_t)__popcll(same));
+      todo &= ~same;
+    }
+  } else {
+    twice_add(twice, counters);
+  }
 }
 
 // labk of every position the border list does not cover: expanding points take their component's rank,

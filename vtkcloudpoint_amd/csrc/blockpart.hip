@@ -760,7 +760,8 @@ __global__ __launch_bounds__(BIG ? 1024 : 128) void k_blk_sort(const Rec32* __re
                                                                Desc* __restrict__ fall, uint32_t* __restrict__ gcnt,
                                                                KeyPart* __restrict__ stage_g, uint32_t* __restrict__ rk_g,
                                                                double* __restrict__ motor_bm, uint32_t* __restrict__ bl,
-                                                               uint32_t* __restrict__ blk_t, uint32_t b_lo, int has_dropped) {
+                                                               uint32_t* __restrict__ blk_t, uint32_t b_lo, int has_dropped,
+                                                               int32_t* __restrict__ grp_big, uint32_t brute_thr) {
   constexpr int NT = BIG ? 1024 : 128;
   constexpr uint32_t SBMAX = BIG ? 8192u : 512u;
   constexpr uint32_t PER = SBMAX / NT;
@@ -798,6 +799,8 @@ __global__ __launch_bounds__(BIG ? 1024 : 128) void k_blk_sort(const Rec32* __re
       if (e == s || e - s > VCP_BIG_BLOCK) return;
     }
     const uint32_t m = e - s;
+    // what the grid engine reads as the point's group: the points of blocks small enough for the all-pairs kernel are not its
+    const int32_t gb = ((BIG || LIST) ? blockstart[b + 1] - blockstart[b] : m) > brute_thr ? (int32_t)b : -1;
     if (threadIdx.x == 0) {
       s_k[0] = ~0ull;
       s_k[1] = 0ull;
@@ -933,6 +936,7 @@ __global__ __launch_bounds__(BIG ? 1024 : 128) void k_blk_sort(const Rec32* __re
         *reinterpret_cast<double2*>(motor_bm + 2 * (size_t)p) = make_double2(x.x, x.y);
         bl[p] = x.idx;
         blk_t[p] = b;
+        if (grp_big) grp_big[p] = gb;
       }
     } else {
 #pragma unroll
@@ -949,6 +953,7 @@ __global__ __launch_bounds__(BIG ? 1024 : 128) void k_blk_sort(const Rec32* __re
           *reinterpret_cast<double2*>(motor_bm + 2 * (size_t)p) = make_double2(r[u].x, r[u].y);
           bl[p] = r[u].idx;
           blk_t[p] = b;
+          if (grp_big) grp_big[p] = gb;
         }
       }
     }
@@ -1129,6 +1134,16 @@ int vcp_blocks_build(vcp_ctx* ctx, BlocksState* s, uint32_t S_lo, uint32_t S_hi,
   VCP_TRY(vcp_blocks_ens(ctx, s->bl, nl * 4));
   VCP_TRY(vcp_blocks_ens(ctx, s->motor_bm, nl * 16));
   VCP_TRY(vcp_blocks_ens(ctx, s->blk_t, (nl + 1) * 4));
+  {
+    // blocks of up to this many points go to the all-pairs kernel (VCP_BRUTE_MAX: test switch, 0 = every block to the engine)
+    static const int brute_env = [] {
+      const char* e = getenv("VCP_BRUTE_MAX");
+      const int v = e ? atoi(e) : 1024;
+      return v < 0 ? 0 : v > (int)VCP_BRUTE_MAX ? (int)VCP_BRUTE_MAX : v;
+    }();
+    s->brute_thr = (uint32_t)brute_env;
+    if (s->brute_thr) VCP_TRY(vcp_blocks_ens(ctx, s->grp_big, (nl + 1) * 4));
+  }
   // large blocks: descriptors, slices, sub-ranges (V <= m / 128 each, at least 2) and the general kernel's list
   const size_t nbig_cap = nl / VCP_BIG_BLOCK + 8, nvirt_cap = nl / 64 + 2 * nbig_cap + 64;
   VCP_TRY(vcp_blocks_ens(ctx, s->biglist, nbig_cap * 4));
@@ -1163,7 +1178,7 @@ int vcp_blocks_build(vcp_ctx* ctx, BlocksState* s, uint32_t S_lo, uint32_t S_hi,
                        S_lo, S_hi, off0);
 #define VCP_SORT_ARGS(list) rec2, rec, blockstart, nblocks, list, d_sel, fall, gcnt, s->stage.as<KeyPart>(),              \
                             s->rank.as<uint32_t>(), s->motor_bm.as<double>(), s->bl.as<uint32_t>(), s->blk_t.as<uint32_t>(), \
-                            b_lo, has_dropped ? 1 : 0
+                            b_lo, has_dropped ? 1 : 0, s->brute_thr ? s->grp_big.as<int32_t>() : nullptr, s->brute_thr
     if (s->b_hi > s->b_lo)
       hipLaunchKernelGGL((k_blk_sort<false, false>), dim3(nbl), dim3(128), 0, st, VCP_SORT_ARGS(nullptr));
     const unsigned gsl = (unsigned)std::min<size_t>(2048, nbig_cap + nl / SLICE);

@@ -475,6 +475,251 @@ int blocks_begin(vcp_ctx* ctx, const double* d_motor_in, bool from_host, const d
   return VCP_OK;
 }
 
+// ---- cluster: small blocks ---------------------------------------------------------------------------------------
+// A block of a few hundred points needs no grid: its coordinates fit in LDS and DBImproved's three facts (BaseClass/
+// DBImproved.cs: core test :33-54, transitive expansion :56-90, border rule :87) come from all-pairs passes over them --
+// for the sparse background of a scan (most blocks, no core point at all) that is one pass of n_b^2 predicate evaluations
+// on binary64 registers against a broadcast LDS read, where the grid engine bins, sorts and tables every point over tens
+// of empty cells each.  One workgroup per block of at most BRUTE_CAP points; larger blocks (the dense ones) take the
+// grouped engine.  Same canonical formulation as the engine (dbscan.hip): a cluster's seed is its core point of smallest
+// list position, clusters are numbered by seed, a border point takes the largest adjacent cluster and counts as "queried
+// twice" when it precedes the seed of the smallest one.
+__global__ void k_zero_words(uint32_t* __restrict__ p, uint32_t n) {
+  for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) p[k] = 0u;
+}
+constexpr int BRT = 256;
+constexpr uint32_t BRUTE_CAP = VCP_BRUTE_MAX;
+constexpr int BRP = (int)(BRUTE_CAP / BRT);  // points per thread
+
+__device__ __forceinline__ uint32_t brute_find(volatile uint32_t* par, uint32_t x) {
+  for (;;) {
+    const uint32_t y = par[x];
+    if (y == x) return x;
+    x = y;
+  }
+}
+// link the trees of a and b (the smaller index becomes the root: a component's root is its seed)
+__device__ __forceinline__ void brute_unite(uint32_t* par, uint32_t a, uint32_t b) {
+  for (;;) {
+    a = brute_find(par, a);
+    b = brute_find(par, b);
+    if (a == b) return;
+    const uint32_t hi = max(a, b), lo = min(a, b);
+    if (atomicCAS(&par[hi], hi, lo) == hi) return;
+  }
+}
+
+// d = max(x - x_Min, y - y_Min), the partition's sort key (blockpart.hip: dkey)
+__device__ __forceinline__ double brute_d(const double2 v, double x_Min, double y_Min) {
+  const double a = v.x - x_Min, b = v.y - y_Min;
+  return a > b ? a : b;
+}
+
+// The window of candidates.  d is 1-Lipschitz in the maximum norm, so two points within eps (L1) of each other have d values
+// within eps -- and the block's points are stored in the order of d (FrmMain.cs:1229-1251, inside a block the order of the
+// sorted list): the neighbours of the wave's 64 consecutive points lie between the first position whose d reaches
+// d(first) - eps and the last whose d stays below d(last) + eps (a hair of slack for the rounding of the subtractions; the
+// predicate itself stays the exact one).  On the sparse background that is a few percent of the block.  The kernel does not
+// TRUST the order: it checks that d is non-decreasing over the block and takes every position otherwise (a block ordered
+// by other coordinates: vcp_blocks_begin_keyed).
+struct BruteWin {
+  uint32_t lo, hi;
+};
+__device__ __forceinline__ BruteWin brute_window(const double2* pt, uint32_t ng, uint32_t first, uint32_t last, double eps,
+                                                 double x_Min, double y_Min, bool sorted) {
+  BruteWin wn{0u, ng};
+  if (!sorted) return wn;
+  const double df = brute_d(pt[first], x_Min, y_Min), dl = brute_d(pt[last], x_Min, y_Min);
+  const double lo_v = df - eps - (fabs(df) + eps) * 0x1p-40, hi_v = dl + eps + (fabs(dl) + eps) * 0x1p-40;
+  if (!(lo_v <= df) || !(hi_v >= dl)) return wn;  // eps is a NaN (nothing is within it) or negative: no shortcut
+  uint32_t a = 0u, b = first;  // first position in [0, first] whose d >= lo_v (d(first) itself is)
+  while (a < b) {
+    const uint32_t mid = (a + b) >> 1;
+    if (brute_d(pt[mid], x_Min, y_Min) >= lo_v) b = mid;
+    else a = mid + 1u;
+  }
+  wn.lo = a;
+  a = last + 1u;
+  b = ng;  // first position in (last, ng] whose d > hi_v
+  while (a < b) {
+    const uint32_t mid = (a + b) >> 1;
+    if (brute_d(pt[mid], x_Min, y_Min) > hi_v) b = mid;
+    else a = mid + 1u;
+  }
+  wn.hi = a;
+  return wn;
+}
+
+__global__ __launch_bounds__(BRT) void k_block_brute(const double* __restrict__ motor_bm, const uint32_t* __restrict__ blockstart,
+                                                    uint32_t lo, uint32_t thr_small, double eps, int min_pts, double x_Min,
+                                                    double y_Min, int32_t* __restrict__ d_local,
+                                                    uint32_t* __restrict__ gtwice, uint32_t* __restrict__ gnclus,
+                                                    unsigned long long* __restrict__ counters) {
+  const uint32_t b = lo + blockIdx.x;
+  const uint32_t s0 = blockstart[b], ng = blockstart[b + 1] - s0;
+  if (ng > thr_small) return;
+  if (ng == 0) {
+    if (threadIdx.x == 0) gtwice[b] = gnclus[b] = 0u;
+    return;
+  }
+  __shared__ double2 pt[BRUTE_CAP];
+  __shared__ uint32_t par[BRUTE_CAP];   // core points: parent in the forest; NONE32 otherwise
+  __shared__ uint32_t rnk[BRUTE_CAP];   // at roots: the cluster's rank among the block's clusters
+  __shared__ uint32_t wsum[BRT / 64];
+  __shared__ uint32_t s_twice, s_any, s_unsorted;
+  const uint32_t t = threadIdx.x;
+  const int lane = t & 63, w = t >> 6;
+  const double2* src = reinterpret_cast<const double2*>(motor_bm) + s0;
+  for (uint32_t j = t; j < ng; j += BRT) pt[j] = src[j];
+  if (t == 0) s_twice = s_any = s_unsorted = 0u;
+  __syncthreads();
+  double ax[BRP], ay[BRP];
+  uint32_t c[BRP];
+  {
+    bool bad = false;
+#pragma unroll
+    for (int u = 0; u < BRP; u++) {
+      const uint32_t p = t + (uint32_t)u * BRT;
+      const double2 a = p < ng ? pt[p] : make_double2(NAN, NAN);  // (a NaN is within eps of nothing)
+      ax[u] = a.x;
+      ay[u] = a.y;
+      c[u] = 0u;
+      if (p > 0u && p < ng && !(brute_d(pt[p - 1u], x_Min, y_Min) <= brute_d(a, x_Min, y_Min))) bad = true;
+    }
+    if (__ballot(bad) != 0ull && lane == 0) s_unsorted = 1u;
+  }
+  __syncthreads();
+  const bool sorted = s_unsorted == 0u;
+  // the wave's candidate windows, one per round of 256 points (uniform over the wave)
+  BruteWin wn[BRP];
+#pragma unroll
+  for (int u = 0; u < BRP; u++) {
+    const uint32_t first = (uint32_t)u * BRT + (uint32_t)w * 64u;
+    wn[u].lo = wn[u].hi = 0u;
+    if (first < ng) wn[u] = brute_window(pt, ng, first, min(first + 63u, ng - 1u), eps, x_Min, y_Min, sorted);
+  }
+  // 1. neighbours within eps (itself included)
+#pragma unroll
+  for (int u = 0; u < BRP; u++) {
+    uint32_t cc = 0u;
+    const double x = ax[u], y = ay[u];
+#pragma unroll 4
+    for (uint32_t j = wn[u].lo; j < wn[u].hi; j++) {
+      const double2 q = pt[j];
+      cc += (fabs(x - q.x) + fabs(y - q.y) <= eps) ? 1u : 0u;
+    }
+    c[u] = cc;
+  }
+  bool core[BRP];
+  uint32_t anycore = 0u;
+#pragma unroll
+  for (int u = 0; u < BRP; u++) {
+    const uint32_t p = t + (uint32_t)u * BRT;
+    core[u] = p < ng && (int)c[u] >= min_pts;
+    if (p < ng) par[p] = core[u] ? p : NONE32;
+    anycore |= core[u] ? 1u : 0u;
+  }
+  if (__ballot(anycore) != 0ull && lane == 0) s_any = 1u;
+  __syncthreads();
+  if (s_any == 0u) {  // no core point: every point is noise, no cluster (uniform over the workgroup)
+    for (uint32_t j = t; j < ng; j += BRT) d_local[s0 + j] = 0;
+    if (t == 0) {
+      gtwice[b] = gnclus[b] = 0u;
+      atomicAdd(&counters[2 * (b & 63u)], (unsigned long long)ng * (unsigned long long)ng);
+    }
+    return;
+  }
+  // from here on the LDS copy serves as the list of CORE points: the others get a NaN abscissa, within eps of nothing
+  // (the windows were taken from the unchanged copy above)
+#pragma unroll
+  for (int u = 0; u < BRP; u++) {
+    const uint32_t p = t + (uint32_t)u * BRT;
+    if (p < ng && !core[u]) pt[p].x = NAN;
+  }
+  __syncthreads();
+  // 2. components of the core points: a core point links to every core point before it
+#pragma unroll
+  for (int u = 0; u < BRP; u++) {
+    if (__ballot(core[u]) == 0ull) continue;  // (uniform over the wave)
+    const uint32_t p = t + (uint32_t)u * BRT;
+    const uint32_t wend = min(wn[u].hi, (uint32_t)u * BRT + (uint32_t)w * 64u + 64u);  // up to the wave's last point
+    const double x = core[u] ? ax[u] : NAN, y = ay[u];
+    for (uint32_t j = wn[u].lo; j < wend; j++) {
+      const double2 q = pt[j];
+      if (j < p && fabs(x - q.x) + fabs(y - q.y) <= eps) brute_unite(par, p, j);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < BRP; u++) {
+    const uint32_t p = t + (uint32_t)u * BRT;
+    if (core[u]) {
+      const uint32_t r = brute_find(par, p);
+      // (a root keeps itself; writing other entries while neighbours still walk through them is safe: every value ever
+      // stored in par[p] is an ancestor of p)
+      if (r != p) par[p] = r;
+    }
+  }
+  __syncthreads();
+  // ranks of the roots in index order = numbering by seed
+  uint32_t run = 0u;
+#pragma unroll
+  for (int u = 0; u < BRP; u++) {
+    if ((uint32_t)u * BRT >= ng) break;
+    const uint32_t p = t + (uint32_t)u * BRT;
+    const bool root = core[u] && par[p] == p;
+    const unsigned long long m = __ballot(root);
+    if (lane == 0) wsum[w] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = run;
+    for (int k = 0; k < w; k++) before += wsum[k];
+    if (root) rnk[p] = before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    for (int k = 0; k < BRT / 64; k++) run += wsum[k];
+    __syncthreads();
+  }
+  const uint32_t kg = run;
+  // 3. labels: core points their component; the others the largest adjacent cluster (roots are in rank order)
+  uint32_t twice = 0u;
+#pragma unroll
+  for (int u = 0; u < BRP; u++) {
+    if ((uint32_t)u * BRT >= ng) break;
+    const uint32_t p = t + (uint32_t)u * BRT;
+    const bool cand = p < ng && !core[u] && c[u] > 1u;
+    uint32_t mxr = 0u, mnr = NONE32;
+    bool any = false;
+    if (__ballot(cand) != 0ull) {
+      const double x = cand ? ax[u] : NAN, y = ay[u];
+      for (uint32_t j = wn[u].lo; j < wn[u].hi; j++) {
+        const double2 q = pt[j];
+        if (fabs(x - q.x) + fabs(y - q.y) <= eps) {
+          const uint32_t r = par[j];
+          mxr = max(mxr, r);
+          mnr = min(mnr, r);
+          any = true;
+        }
+      }
+    }
+    if (p < ng) {
+      int32_t lab = 0;
+      if (core[u]) lab = (int32_t)rnk[par[p]] + 1;
+      else if (any) {
+        lab = (int32_t)rnk[mxr] + 1;
+        if (p < mnr) twice++;
+      }
+      d_local[s0 + p] = lab;
+    }
+  }
+  if (twice) atomicAdd(&s_twice, twice);
+  __syncthreads();
+  if (t == 0) {
+    const uint32_t tw = s_twice;
+    gtwice[b] = tw;
+    gnclus[b] = kg;
+    atomicAdd(&counters[2 * (b & 63u)], (unsigned long long)ng * ((unsigned long long)ng + kg + tw));
+    atomicAdd(&counters[2 * (b & 63u) + 1], (unsigned long long)kg);
+  }
+}
+
 int blocks_cluster(vcp_ctx* ctx, int32_t lo, int32_t hi, int32_t* d_local, int64_t* evals_o) {
   BlocksState* s = ctx->blocks;
   if (!s || !s->ready) return vcp_fail(ctx, VCP_ERR_ARG, "vcp_blocks_begin has not run");
@@ -484,8 +729,32 @@ int blocks_cluster(vcp_ctx* ctx, int32_t lo, int32_t hi, int32_t* d_local, int64
   if (evals_o) *evals_o = 0;
   if (lo == hi) return VCP_OK;
   if (s->m == 0) return VCP_OK;
+  // blocks of at most brute_thr points: all pairs in LDS; the others: one grouped launch of the grid engine, which sees
+  // the points of the small blocks as excluded (group -1 in grp_big, written by the partition)
+  const uint32_t thr = s->brute_thr;
+  uint64_t pts_small = 0, pts_big = 0;
+  if (thr > 0) {
+    for (int64_t b = lo; b < hi; b++) {
+      const uint32_t c = s->h_blockstart[(size_t)b + 1] - s->h_blockstart[(size_t)b];
+      if (c <= thr) pts_small += c;
+      else pts_big += c;
+    }
+  } else {
+    pts_big = 1;
+  }
+  unsigned long long* bc = nullptr;  // [64][2]: op counter, clusters of the small blocks
+  if (pts_small > 0) {
+    VCP_TRY(ens(ctx, s->brutecnt, 128 * sizeof(unsigned long long)));
+    bc = s->brutecnt.as<unsigned long long>();
+    hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(BT), 0, ctx->stream, reinterpret_cast<uint32_t*>(bc), 256u);
+  }
+  int64_t ev = 0;
+  int32_t cf = 0;
+  if (pts_big > 0) {
   DbscanExt ext;
-  ext.d_group = reinterpret_cast<const int32_t*>(s->blk_t.as<uint32_t>());  // block id per block-major position
+  ext.d_group = thr > 0 ? s->grp_big.as<int32_t>()
+                        : reinterpret_cast<const int32_t*>(s->blk_t.as<uint32_t>());  // block id per block-major position
+  ext.skip_upto = thr;
   ext.d_ord = nullptr;                                                        // list position = input index
   ext.d_groupstart = s->blockstart.as<uint32_t>();
   ext.G = (int32_t)s->nblocks;
@@ -495,13 +764,26 @@ int blocks_cluster(vcp_ctx* ctx, int32_t lo, int32_t hi, int32_t* d_local, int64
   ext.d_group_nclus = s->gnclus.as<uint32_t>();
   const double bbox[6] = {s->mbox[0], s->mbox[2], 0.0, s->mbox[1], s->mbox[3], 0.0};  // the partition has seen every point
   ext.h_bbox = bbox;
-  int64_t ev = 0;
-  int32_t cf = 0;
   // input = the m points that fell in a block, in block-major order; positions outside [lo, hi)'s slice get 0
   VCP_TRY(vcp_dbscan_engine(ctx, s->motor_bm.as<double>(), s->m, 2, VCP_L1_2D, s->eps, s->min_pts, 0, nullptr, d_local,
                             nullptr, nullptr, &cf, &ev, &ext));
-  VCP_HIP(ctx, hipGetLastError());
-  VCP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (pts_small > 0) {
+    hipLaunchKernelGGL(k_block_brute, dim3((unsigned)(hi - lo)), dim3(BRT), 0, ctx->stream, s->motor_bm.as<double>(),
+                       s->blockstart.as<uint32_t>(), (uint32_t)lo, thr, s->eps, s->min_pts, s->x_Min, s->y_Min, d_local, s->gtwice.as<uint32_t>(),
+                       s->gnclus.as<uint32_t>(), bc);
+    unsigned long long* hb = reinterpret_cast<unsigned long long*>(ctx->pinned) + 128;
+    VCP_HIP(ctx, hipMemcpyAsync(hb, bc, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    VCP_HIP(ctx, hipGetLastError());
+    VCP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 64; k++) {
+      ev += (int64_t)hb[2 * k];
+      cf += (int32_t)hb[2 * k + 1];
+    }
+  } else {
+    VCP_HIP(ctx, hipGetLastError());
+    VCP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
   if (evals_o) *evals_o = ev;
   // the clusters of the blocks clustered so far (the finish stage sizes its arrays with it when every block is in)
   if (lo == s->cov_hi) {
@@ -746,7 +1028,7 @@ void vcp_blocks_state_free(vcp_ctx* ctx) {
                    &s->gtwice, &s->gnclus, &s->tmp0, &s->tmp1, &s->tmp2, &s->tmp3, &s->sorttmp, &s->blk_t, &s->csize,
                    &s->cstart, &s->kb, &s->zb, &s->keep, &s->order, &s->newlab, &s->zflag, &s->zlist, &s->zcoords,
                    &s->zlab, &s->misc, &s->biglist, &s->sel, &s->cand, &s->counts, &s->rec, &s->rec2, &s->stage, &s->rank, &s->binfo, &s->slicelist,
-                   &s->vlist, &s->fall, &s->gcnt};
+                   &s->vlist, &s->fall, &s->gcnt, &s->grp_big, &s->brutecnt};
   for (DevBuf* b : all)
     if (b->p) (void)hipFree(b->p);
   delete s;

@@ -18,6 +18,10 @@ struct BlocksState {
       cstart, kb, zb, keep, order, newlab, zflag, zlist, zcoords, zlab, misc;
   // partition workspace (blockpart.hip)
   DevBuf sel, cand, counts, rec, rec2, stage, rank, binfo, slicelist, vlist, fall, gcnt;
+  // blocks of at most brute_thr points are clustered by the all-pairs kernel (blocks.hip: k_block_brute), the others by the
+  // grid engine, which reads grp_big [m]: the block id of a point of a larger block, -1 for the others (0 = engine only)
+  uint32_t brute_thr = 0;
+  DevBuf grp_big, brutecnt;
   bool virt_clean = false;  // gcnt is all zero
   // the plan (identical on every rank) ...
   bool planned = false, built = false;
@@ -45,6 +49,7 @@ struct BlocksState {
 };
 
 constexpr uint32_t VCP_BIG_BLOCK = 1024;  // blocks beyond this take the workgroup-per-block kernels
+constexpr uint32_t VCP_BRUTE_MAX = 1024;  // largest block the all-pairs kernel takes (its LDS copy of the coordinates)
 
 // ensure capacity of a state-owned buffer (contents are NOT preserved)
 int vcp_blocks_ens(vcp_ctx* ctx, DevBuf& b, size_t bytes);

@@ -587,8 +587,10 @@ struct CoreTile<2> {  // 3 rows x 512 x 8 B = 12 KB (+ slack: a lane's last trip
     c[1] = v.y;
   }
 };
-// (A 3-D tile -- 9 rows x 384 x 12 B -- was built and measured: 1.79 ms against 1.20 ms for the global-memory loop on the
-// 10 M-point L2_3D cloud.  41 KB of LDS leave three workgroups per CU and dense cells overflow the tile; 3-D keeps k_core.)
+// (A 3-D tile was built and measured twice.  Round 2: 9 rows x 384 x 12 B with 32-bit hit masks, 1.79 ms against 1.20 ms
+// for the global-memory loop on the 10 M-point L2_3D cloud.  Round 3: 9 rows x 320 as three coordinate planes (35 KB, four
+// workgroups per CU, 82 VGPRs) with 64-bit hit masks, 1.32 ms against 0.90 ms.  Nine rows of tile bounds, loads and
+// barriers per workgroup cost more than the L2 hits of the direct loop save; 3-D keeps k_core.)
 
 // row bounds of this lane (rs >= re for a missing row) and the workgroup's union per row in t.lo / t.hi;
 // returns true when every range fits the tile (uniform over the workgroup)
@@ -1394,7 +1396,7 @@ __global__ __launch_bounds__(TPB) void k_group_stats(int32_t G, int glo, int ghi
                                                     const uint32_t* __restrict__ seedpref,
                                                     const uint32_t* __restrict__ group_twice,
                                                     uint32_t* __restrict__ group_nclus,
-                                                    unsigned long long* __restrict__ evals) {
+                                                    unsigned long long* __restrict__ evals, uint32_t skip_upto) {
   int g = blockIdx.x * TPB + threadIdx.x;
   if (g >= G) return;
   if (g < glo || g >= ghi) {
@@ -1402,6 +1404,7 @@ __global__ __launch_bounds__(TPB) void k_group_stats(int32_t G, int glo, int ghi
     return;
   }
   unsigned long long ng = groupstart[g + 1] - groupstart[g];
+  if (ng <= skip_upto) return;  // (DbscanExt::skip_upto)
   unsigned long long kg = seed_rank(seedbits, seedpref, groupstart[g + 1]) - seed_rank(seedbits, seedpref, groupstart[g]);
   if (group_nclus) group_nclus[g] = (uint32_t)kg;
   unsigned long long ev = ng * (ng + kg + group_twice[g]);
@@ -2018,7 +2021,7 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
                        counters);
   if (GROUPED) {
     hipLaunchKernelGGL(k_group_stats, dim3(vcp_blocks(G, TPB)), dim3(TPB), 0, st, G, glo, ghi, ext->d_groupstart,
-                       seedflag, seedpref, ext->d_group_twice, ext->d_group_nclus, counters + 3);
+                       seedflag, seedpref, ext->d_group_twice, ext->d_group_nclus, counters + 3, ext->skip_upto);
     if (ext->d_group_evals)
       VCP_HIP(ctx, hipMemcpyAsync(ext->d_group_evals, counters + 3, 8, hipMemcpyDeviceToDevice, st));
   }

@@ -22,6 +22,9 @@ struct DbscanExt {
   // a box the caller already knows to contain every (finite) input point -- {min x, y, z, max x, y, z}: the bounds pass
   // and its host round trip are skipped (any box is correct: cell indices are clamped; a tight one gives the best grid)
   const double* h_bbox = nullptr;
+  // grouped calls: groups of at most this many points are somebody else's (their points carry group -1): no statistics
+  // are written for them
+  uint32_t skip_upto = 0;
 };
 
 // d_* are device pointers; cf_out / dist_evals host pointers (may be null).  stride = doubles per point.

@@ -175,6 +175,10 @@ __global__ __launch_bounds__(NW == 1 ? BT : 64 * NW) void k_block_order(const in
     for (uint32_t t = s0 + tid; t < s1; t += nthr) order[t] = t;  // (what the rest of this pass reads stays in range)
     return;  // (uniform per wave, and per workgroup for NW > 1)
   }
+  if (K == 0u) {  // nothing but noise (most blocks of a scan's background): the order is the list's
+    for (uint32_t t = s0 + tid; t < s1; t += nthr) order[t] = t;
+    return;  // (uniform per wave, and per workgroup for NW > 1)
+  }
   for (uint32_t k = tid; k <= K; k += nthr) cnt[g][k] = 0;
   if (NW == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();
   for (uint32_t t = s0 + tid; t < s1; t += nthr) atomicAdd(&cnt[g][local[t]], 1u);
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(NW == 1 ? BT : 64 * NW) void k_block_order(const in
       unsigned long long todo = __ballot(mine);
       while (todo) {
         const int first = __ffsll((long long)todo) - 1;
-        const uint32_t cur = (uint32_t)__shfl((int)id, first, 64);
+        const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)id, first);  // (first is uniform: a scalar lane select)
         const unsigned long long same = __ballot(mine && id == cur);
         const uint32_t base = cnt[g][cur];
         if (mine && id == cur) order[base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = t;
@@ -228,6 +232,90 @@ __global__ __launch_bounds__(NW == 1 ? BT : 64 * NW) void k_block_order(const in
         __builtin_amdgcn_wave_barrier();
         todo &= ~same;
       }
+    }
+  }
+}
+// Large blocks (the host's list), second form: one workgroup of 16 waves per block, wave w owns the w-th contiguous segment
+// of the block.  Counts per (id, wave) in LDS, ONE flat exclusive scan in (id, wave) order -- which is the stable order --
+// and every wave places its own segment with its own cursors: each position is read twice by one wave (k_block_order<16>
+// has every wave read the whole block: 146 us for the thousand large blocks of the 10 M-point cloud).
+constexpr int OBW = 16;
+constexpr int OBS = OBW + 1;  // row stride of the counters: the lanes of a wave (same w, different ids) hit different banks
+__global__ __launch_bounds__(64 * OBW) void k_block_order_big(const int32_t* __restrict__ local,
+                                                              const uint32_t* __restrict__ blockstart,
+                                                              const uint32_t* __restrict__ kb,
+                                                              const uint32_t* __restrict__ biglist,
+                                                              const uint32_t* __restrict__ cstart, uint32_t* __restrict__ csize,
+                                                              uint32_t* __restrict__ order, uint32_t* __restrict__ ovf,
+                                                              uint32_t b_lo) {
+  constexpr uint32_t NT = 64 * OBW;
+  constexpr uint32_t EMAX = (uint32_t)(CS_CAP + 1) * OBS;
+  constexpr uint32_t PER = (EMAX + NT - 1) / NT;
+  __shared__ uint32_t cnt[PER * NT + 1];
+  __shared__ uint32_t wsum[OBW];
+  const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+  const int64_t b = (int64_t)biglist[blockIdx.x] - (int64_t)b_lo;
+  const uint32_t s0 = blockstart[b], s1 = blockstart[b + 1];
+  const uint32_t K = kb[b];  // ids 0..K
+  if (K > (uint32_t)CS_CAP || K == 0u) {  // (uniform over the workgroup)
+    if (K != 0u && tid == 0) *ovf = 1u;   // more ids than the LDS table: the host repeats the stage in the library-sort form
+    for (uint32_t t = s0 + tid; t < s1; t += NT) order[t] = t;  // nothing but noise: the order is the list's
+    return;
+  }
+  const uint32_t E = (K + 1u) * OBS;
+  for (uint32_t k = tid; k < PER * NT + 1u; k += NT) cnt[k] = 0u;
+  const uint32_t seg = (((s1 - s0) + OBW - 1u) / OBW + 63u) & ~63u;
+  const uint32_t my0 = min(s0 + w * seg, s1), my1 = min(my0 + seg, s1);
+  __syncthreads();
+  for (uint32_t t = my0 + lane; t < my1; t += 64u) atomicAdd(&cnt[(uint32_t)local[t] * OBS + w], 1u);
+  __syncthreads();
+  {  // flat exclusive scan of cnt[0..E] (+ s0): thread t owns PER consecutive entries
+    uint32_t v[PER], loc = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+      v[k] = cnt[tid * PER + k];
+      loc += v[k];
+    }
+    uint32_t inc = loc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t x = __shfl_up(inc, d, 64);
+      if ((int)lane >= d) inc += x;
+    }
+    if (lane == 63u) wsum[w] = inc;
+    __syncthreads();
+    uint32_t cum = s0 + inc - loc;
+    for (uint32_t k = 0; k < w; k++) cum += wsum[k];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+      cnt[tid * PER + k] = cum;
+      cum += v[k];
+    }
+  }
+  __syncthreads();
+  {  // the sizes of the clusters 1..K (k_keep): the distance between the first cursors of consecutive ids
+    const uint32_t c0 = cstart[b];
+    for (uint32_t k = 1u + tid; k <= K; k += NT) csize[c0 + k - 1u] = cnt[(k + 1u) * OBS] - cnt[k * OBS];
+  }
+  __syncthreads();
+  (void)E;
+  uint32_t idn = my0 + lane < my1 ? (uint32_t)local[my0 + lane] : 0xFFFFFFFFu;
+  for (uint32_t t0 = my0; t0 < my1; t0 += 64u) {
+    const uint32_t t = t0 + lane;
+    const uint32_t id = idn;
+    idn = t + 64u < my1 ? (uint32_t)local[t + 64u] : 0xFFFFFFFFu;  // (the next chunk's ids are on their way)
+    const bool mine = t < my1;
+    unsigned long long todo = __ballot(mine);
+    while (todo) {
+      const int first = __ffsll((long long)todo) - 1;
+      const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)id, first);  // (first is uniform: a scalar lane select)
+      const unsigned long long same = __ballot(mine && id == cur);
+      const uint32_t base = cnt[cur * OBS + w];
+      if (mine && id == cur) order[base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = t;
+      __builtin_amdgcn_wave_barrier();
+      if ((int)lane == first) cnt[cur * OBS + w] = base + (uint32_t)__popcll(same);
+      __builtin_amdgcn_wave_barrier();
+      todo &= ~same;
     }
   }
 }
@@ -308,44 +396,62 @@ struct BandP {
   double x_Min, x_Max, y_Min, y_Max, cell_x, cell_y, r2;
   int rows, cols, all_active;
 };
+// Both sets leave the kernel as BITMAPS over the final order u (one word per 32 positions) plus the words' populations, whose
+// exclusive scans (m / 32 entries instead of m) give every position its rank: zcnt / acnt [nw + 2], zbits / abits [nw].
 __global__ __launch_bounds__(BT) void k_zero_flag(const int32_t* __restrict__ newlab, const uint32_t* __restrict__ order,
-                                                 int64_t m, uint32_t* __restrict__ zflag, const int32_t* __restrict__ local,
-                                                 const double* __restrict__ motor_bm, const uint32_t* __restrict__ blk_t,
-                                                 BandP B, uint32_t* __restrict__ aflag) {
-  int64_t u = (int64_t)blockIdx.x * BT + threadIdx.x;
+                                                 int64_t m, uint32_t* __restrict__ zcnt, uint32_t* __restrict__ zbits,
+                                                 const int32_t* __restrict__ local, const double* __restrict__ motor_bm,
+                                                 const uint32_t* __restrict__ blk_t, BandP B, uint32_t* __restrict__ acnt,
+                                                 uint32_t* __restrict__ abits) {
+  const int64_t u = (int64_t)blockIdx.x * BT + threadIdx.x;
+  const int64_t nw = (m + 31) / 32;
   if (u == 0) {  // the scans read one entry more
-    zflag[m] = zflag[m + 1] = 0u;
-    aflag[m] = aflag[m + 1] = 0u;
+    zcnt[nw] = zcnt[nw + 1] = 0u;
+    acnt[nw] = acnt[nw + 1] = 0u;
   }
-  if (u >= m) return;
-  const uint32_t t = order[u];
-  const bool z = newlab[t] == 0;
-  zflag[u] = z ? 1u : 0u;
-  bool act = z;
-  if (z && !B.all_active && local[t] == 0) {  // noise inside its block: active only near the rectangle's boundary
-    const double2 v = *reinterpret_cast<const double2*>(motor_bm + 2 * (size_t)t);
-    const int b = (int)blk_t[t], p = b / B.cols, q = b - p * B.cols;
-    // the rectangle as FrmMain.cs:1262-1285 evaluates it (last row / column stretched to the max)
-    const double lox = B.x_Min + (double)q * B.cell_x, hix = q == B.cols - 1 ? B.x_Max : B.x_Min + (double)(q + 1) * B.cell_x;
-    const double loy = B.y_Min + (double)p * B.cell_y, hiy = p == B.rows - 1 ? B.y_Max : B.y_Min + (double)(p + 1) * B.cell_y;
-    act = !(v.x - lox > B.r2 && hix - v.x > B.r2 && v.y - loy > B.r2 && hiy - v.y > B.r2);
+  bool z = false, act = false;
+  if (u < m) {
+    const uint32_t t = order[u];
+    z = newlab[t] == 0;
+    act = z;
+    if (z && !B.all_active && local[t] == 0) {  // noise inside its block: active only near the rectangle's boundary
+      const double2 v = *reinterpret_cast<const double2*>(motor_bm + 2 * (size_t)t);
+      const int b = (int)blk_t[t], p = b / B.cols, q = b - p * B.cols;
+      // the rectangle as FrmMain.cs:1262-1285 evaluates it (last row / column stretched to the max)
+      const double lox = B.x_Min + (double)q * B.cell_x, hix = q == B.cols - 1 ? B.x_Max : B.x_Min + (double)(q + 1) * B.cell_x;
+      const double loy = B.y_Min + (double)p * B.cell_y, hiy = p == B.rows - 1 ? B.y_Max : B.y_Min + (double)(p + 1) * B.cell_y;
+      act = !(v.x - lox > B.r2 && hix - v.x > B.r2 && v.y - loy > B.r2 && hiy - v.y > B.r2);
+    }
   }
-  aflag[u] = act ? 1u : 0u;
+  const unsigned long long mz = __ballot(z), ma = __ballot(act);
+  const int lane = threadIdx.x & 63;
+  if ((lane & 31) == 0) {  // lanes 0 and 32 store the wave's two words
+    const int64_t wd = u >> 5;
+    if (wd < nw) {
+      const uint32_t wz = (uint32_t)(mz >> lane), wa = (uint32_t)(ma >> lane);
+      zbits[wd] = wz;
+      abits[wd] = wa;
+      zcnt[wd] = (uint32_t)__popc(wz);
+      acnt[wd] = (uint32_t)__popc(wa);
+    }
+  }
 }
 // merge_order = non-zero entries in final order, then the zero list (FrmMain.cs:1510-1520)
-__global__ __launch_bounds__(BT) void k_compact(const uint32_t* __restrict__ zflag_scan, const int32_t* __restrict__ newlab,
+__global__ __launch_bounds__(BT) void k_compact(const uint32_t* __restrict__ zpre, const uint32_t* __restrict__ zbits,
                                                const uint32_t* __restrict__ order, const uint32_t* __restrict__ bl,
                                                const double* __restrict__ motor_bm, int64_t m, uint32_t Z,
                                                uint32_t* __restrict__ zrank, double* __restrict__ zcoords,
                                                int64_t* __restrict__ merge_order, int swap_xy,
-                                               const uint32_t* __restrict__ aflag_scan) {
+                                               const uint32_t* __restrict__ apre, const uint32_t* __restrict__ abits) {
   int64_t u = (int64_t)blockIdx.x * BT + threadIdx.x;
   if (u >= m) return;
   uint32_t t = order[u];
-  const uint32_t zl = zflag_scan[u];  // rank in the zero list (the merge order's)
-  uint32_t zr = aflag_scan[u];        // rank among the ACTIVE points: the noise pass's list
-  if (newlab[t] == 0) {
-    const bool act = aflag_scan[u + 1] != zr;
+  const uint32_t wd = (uint32_t)(u >> 5), below = (1u << (u & 31)) - 1u;
+  const uint32_t wz = zbits[wd], wa = abits[wd];
+  const uint32_t zl = zpre[wd] + (uint32_t)__popc(wz & below);  // rank in the zero list (the merge order's)
+  const uint32_t zr = apre[wd] + (uint32_t)__popc(wa & below);  // rank among the ACTIVE points: the noise pass's list
+  if ((wz >> (u & 31)) & 1u) {
+    const bool act = (wa >> (u & 31)) & 1u;
     zrank[t] = act ? zr : NONE32;  // where the noise pass will leave this point's label (NONE: stays 0)
     if (merge_order) merge_order[(m - Z) + zl] = (int64_t)bl[t];
     if (!act) return;
@@ -489,7 +595,6 @@ __global__ void k_zero_words(uint32_t* __restrict__ p, uint32_t n) {
 }
 constexpr int BRT = 256;
 constexpr uint32_t BRUTE_CAP = VCP_BRUTE_MAX;
-constexpr int BRP = (int)(BRUTE_CAP / BRT);  // points per thread
 
 __device__ __forceinline__ uint32_t brute_find(volatile uint32_t* par, uint32_t x) {
   for (;;) {
@@ -525,46 +630,63 @@ __device__ __forceinline__ double brute_d(const double2 v, double x_Min, double 
 struct BruteWin {
   uint32_t lo, hi;
 };
-__device__ __forceinline__ BruteWin brute_window(const double2* pt, uint32_t ng, uint32_t first, uint32_t last, double eps,
-                                                 double x_Min, double y_Min, bool sorted) {
-  BruteWin wn{0u, ng};
-  if (!sorted) return wn;
-  const double df = brute_d(pt[first], x_Min, y_Min), dl = brute_d(pt[last], x_Min, y_Min);
+// The window of the GROUP of BRG consecutive points the calling lane's point p belongs to (all lanes of the wave call
+// together; the BRG lanes of a group get the same answer).  It reaches a few positions beyond the group's own: the lanes of
+// the group walk outwards BRG positions at a time, one LDS read and one ballot per step.
+constexpr uint32_t BRG = 8;
+__device__ __forceinline__ BruteWin brute_window(const double2* pt, uint32_t ng, uint32_t p, double eps, double x_Min,
+                                                 double y_Min, bool sorted) {
+  const uint32_t lane = threadIdx.x & 63u, sub = lane & (BRG - 1u), sh = lane & ~(BRG - 1u);
+  const uint32_t first = p & ~(BRG - 1u);
+  const bool active = first < ng;
+  BruteWin wn{0u, active ? ng : 0u};
+  const uint32_t last = active ? min(first + BRG - 1u, ng - 1u) : 0u;
+  const double df = brute_d(pt[active ? first : 0u], x_Min, y_Min), dl = brute_d(pt[last], x_Min, y_Min);
   const double lo_v = df - eps - (fabs(df) + eps) * 0x1p-40, hi_v = dl + eps + (fabs(dl) + eps) * 0x1p-40;
-  if (!(lo_v <= df) || !(hi_v >= dl)) return wn;  // eps is a NaN (nothing is within it) or negative: no shortcut
-  uint32_t a = 0u, b = first;  // first position in [0, first] whose d >= lo_v (d(first) itself is)
-  while (a < b) {
-    const uint32_t mid = (a + b) >> 1;
-    if (brute_d(pt[mid], x_Min, y_Min) >= lo_v) b = mid;
-    else a = mid + 1u;
+  // eps a NaN (nothing is within it) or negative, or a block in another order: no shortcut
+  bool walk = active && sorted && lo_v <= df && hi_v >= dl;
+  uint32_t a = first;  // -> first position in [0, first] whose d >= lo_v
+  bool more = walk;
+  while (__ballot(more) != 0ull) {
+    const bool in = more && a > sub && brute_d(pt[a - 1u - sub], x_Min, y_Min) >= lo_v;
+    const uint32_t bits = (uint32_t)(__ballot(in) >> sh) & ((1u << BRG) - 1u);
+    const uint32_t run = (uint32_t)__ffs((int)(~bits)) - 1u;  // bits has BRG bits: a zero bit at BRG at the latest
+    if (more) {
+      a -= min(run, BRG);
+      more = run >= BRG;
+    }
   }
-  wn.lo = a;
-  a = last + 1u;
-  b = ng;  // first position in (last, ng] whose d > hi_v
-  while (a < b) {
-    const uint32_t mid = (a + b) >> 1;
-    if (brute_d(pt[mid], x_Min, y_Min) > hi_v) b = mid;
-    else a = mid + 1u;
+  if (walk) wn.lo = a;
+  a = last + 1u;  // -> first position in (last, ng] whose d > hi_v
+  more = walk;
+  while (__ballot(more) != 0ull) {
+    const bool in = more && a + sub < ng && brute_d(pt[min(a + sub, ng - 1u)], x_Min, y_Min) <= hi_v;
+    const uint32_t bits = (uint32_t)(__ballot(in) >> sh) & ((1u << BRG) - 1u);
+    const uint32_t run = (uint32_t)__ffs((int)(~bits)) - 1u;
+    if (more) {
+      a += min(run, BRG);
+      more = run >= BRG;
+    }
   }
-  wn.hi = a;
+  if (walk) wn.hi = a;
   return wn;
 }
 
+// CAP = points of LDS: blocks of (above, CAP'] points, CAP' = min(CAP, thr_small).  Two instances: most blocks hold a few
+// hundred points and their workgroups should not reserve the LDS of the largest (6 KB against 24: eight workgroups per CU)
+template <uint32_t CAP>
 __global__ __launch_bounds__(BRT) void k_block_brute(const double* __restrict__ motor_bm, const uint32_t* __restrict__ blockstart,
-                                                    uint32_t lo, uint32_t thr_small, double eps, int min_pts, double x_Min,
+                                                    uint32_t lo, uint32_t above, uint32_t thr_small, double eps, int min_pts, double x_Min,
                                                     double y_Min, int32_t* __restrict__ d_local,
-                                                    uint32_t* __restrict__ gtwice, uint32_t* __restrict__ gnclus,
                                                     unsigned long long* __restrict__ counters) {
   const uint32_t b = lo + blockIdx.x;
   const uint32_t s0 = blockstart[b], ng = blockstart[b + 1] - s0;
-  if (ng > thr_small) return;
-  if (ng == 0) {
-    if (threadIdx.x == 0) gtwice[b] = gnclus[b] = 0u;
-    return;
-  }
-  __shared__ double2 pt[BRUTE_CAP];
-  __shared__ uint32_t par[BRUTE_CAP];   // core points: parent in the forest; NONE32 otherwise
-  __shared__ uint32_t rnk[BRUTE_CAP];   // at roots: the cluster's rank among the block's clusters
+  constexpr int BRP = (int)(CAP / BRT);  // points per thread
+  if (ng > thr_small || ng > CAP || (above > 0u && ng <= above)) return;
+  if (ng == 0) return;
+  __shared__ double2 pt[CAP];
+  __shared__ uint32_t par[CAP];   // core points: parent in the forest; NONE32 otherwise
+  __shared__ uint32_t rnk[CAP];   // at roots: the cluster's rank among the block's clusters
   __shared__ uint32_t wsum[BRT / 64];
   __shared__ uint32_t s_twice, s_any, s_unsorted;
   const uint32_t t = threadIdx.x;
@@ -590,13 +712,13 @@ __global__ __launch_bounds__(BRT) void k_block_brute(const double* __restrict__ 
   }
   __syncthreads();
   const bool sorted = s_unsorted == 0u;
-  // the wave's candidate windows, one per round of 256 points (uniform over the wave)
+  // the candidate windows of the lane's points, one per round of 256 points (shared by the BRG lanes of a group)
   BruteWin wn[BRP];
 #pragma unroll
   for (int u = 0; u < BRP; u++) {
-    const uint32_t first = (uint32_t)u * BRT + (uint32_t)w * 64u;
     wn[u].lo = wn[u].hi = 0u;
-    if (first < ng) wn[u] = brute_window(pt, ng, first, min(first + 63u, ng - 1u), eps, x_Min, y_Min, sorted);
+    if ((uint32_t)u * BRT + (uint32_t)w * 64u < ng)  // (uniform over the wave)
+      wn[u] = brute_window(pt, ng, t + (uint32_t)u * BRT, eps, x_Min, y_Min, sorted);
   }
   // 1. neighbours within eps (itself included)
 #pragma unroll
@@ -623,10 +745,7 @@ __global__ __launch_bounds__(BRT) void k_block_brute(const double* __restrict__ 
   __syncthreads();
   if (s_any == 0u) {  // no core point: every point is noise, no cluster (uniform over the workgroup)
     for (uint32_t j = t; j < ng; j += BRT) d_local[s0 + j] = 0;
-    if (t == 0) {
-      gtwice[b] = gnclus[b] = 0u;
-      atomicAdd(&counters[2 * (b & 63u)], (unsigned long long)ng * (unsigned long long)ng);
-    }
+    if (t == 0) atomicAdd(&counters[2 * (b & 63u)], (unsigned long long)ng * (unsigned long long)ng);
     return;
   }
   // from here on the LDS copy serves as the list of CORE points: the others get a NaN abscissa, within eps of nothing
@@ -642,11 +761,11 @@ __global__ __launch_bounds__(BRT) void k_block_brute(const double* __restrict__ 
   for (int u = 0; u < BRP; u++) {
     if (__ballot(core[u]) == 0ull) continue;  // (uniform over the wave)
     const uint32_t p = t + (uint32_t)u * BRT;
-    const uint32_t wend = min(wn[u].hi, (uint32_t)u * BRT + (uint32_t)w * 64u + 64u);  // up to the wave's last point
-    const double x = core[u] ? ax[u] : NAN, y = ay[u];
+    const uint32_t wend = core[u] ? min(wn[u].hi, p) : 0u;  // the core points before it
+    const double x = ax[u], y = ay[u];
     for (uint32_t j = wn[u].lo; j < wend; j++) {
       const double2 q = pt[j];
-      if (j < p && fabs(x - q.x) + fabs(y - q.y) <= eps) brute_unite(par, p, j);
+      if (fabs(x - q.x) + fabs(y - q.y) <= eps) brute_unite(par, p, j);
     }
   }
   __syncthreads();
@@ -688,8 +807,8 @@ __global__ __launch_bounds__(BRT) void k_block_brute(const double* __restrict__ 
     uint32_t mxr = 0u, mnr = NONE32;
     bool any = false;
     if (__ballot(cand) != 0ull) {
-      const double x = cand ? ax[u] : NAN, y = ay[u];
-      for (uint32_t j = wn[u].lo; j < wn[u].hi; j++) {
+      const double x = ax[u], y = ay[u];
+      for (uint32_t j = wn[u].lo, je = cand ? wn[u].hi : 0u; j < je; j++) {
         const double2 q = pt[j];
         if (fabs(x - q.x) + fabs(y - q.y) <= eps) {
           const uint32_t r = par[j];
@@ -713,8 +832,6 @@ __global__ __launch_bounds__(BRT) void k_block_brute(const double* __restrict__ 
   __syncthreads();
   if (t == 0) {
     const uint32_t tw = s_twice;
-    gtwice[b] = tw;
-    gnclus[b] = kg;
     atomicAdd(&counters[2 * (b & 63u)], (unsigned long long)ng * ((unsigned long long)ng + kg + tw));
     atomicAdd(&counters[2 * (b & 63u) + 1], (unsigned long long)kg);
   }
@@ -733,57 +850,72 @@ int blocks_cluster(vcp_ctx* ctx, int32_t lo, int32_t hi, int32_t* d_local, int64
   // the points of the small blocks as excluded (group -1 in grp_big, written by the partition)
   const uint32_t thr = s->brute_thr;
   uint64_t pts_small = 0, pts_big = 0;
+  bool any_mid = false;  // blocks beyond the small instance of the all-pairs kernel
   if (thr > 0) {
     for (int64_t b = lo; b < hi; b++) {
       const uint32_t c = s->h_blockstart[(size_t)b + 1] - s->h_blockstart[(size_t)b];
       if (c <= thr) pts_small += c;
       else pts_big += c;
+      if (c <= thr && c > (uint32_t)BRT) any_mid = true;
     }
   } else {
     pts_big = 1;
   }
-  unsigned long long* bc = nullptr;  // [64][2]: op counter, clusters of the small blocks
-  if (pts_small > 0) {
-    VCP_TRY(ens(ctx, s->brutecnt, 128 * sizeof(unsigned long long)));
-    bc = s->brutecnt.as<unsigned long long>();
-    hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(BT), 0, ctx->stream, reinterpret_cast<uint32_t*>(bc), 256u);
-  }
+  // The small blocks run on a second stream beside the engine's launches (their outputs are disjoint: positions of d_local,
+  // counters of their own); both are joined before the host reads anything.
   int64_t ev = 0;
   int32_t cf = 0;
-  if (pts_big > 0) {
-  DbscanExt ext;
-  ext.d_group = thr > 0 ? s->grp_big.as<int32_t>()
-                        : reinterpret_cast<const int32_t*>(s->blk_t.as<uint32_t>());  // block id per block-major position
-  ext.skip_upto = thr;
-  ext.d_ord = nullptr;                                                        // list position = input index
-  ext.d_groupstart = s->blockstart.as<uint32_t>();
-  ext.G = (int32_t)s->nblocks;
-  ext.only_lo = lo;
-  ext.only_hi = hi;
-  ext.d_group_twice = s->gtwice.as<uint32_t>();
-  ext.d_group_nclus = s->gnclus.as<uint32_t>();
-  const double bbox[6] = {s->mbox[0], s->mbox[2], 0.0, s->mbox[1], s->mbox[3], 0.0};  // the partition has seen every point
-  ext.h_bbox = bbox;
-  // input = the m points that fell in a block, in block-major order; positions outside [lo, hi)'s slice get 0
-  VCP_TRY(vcp_dbscan_engine(ctx, s->motor_bm.as<double>(), s->m, 2, VCP_L1_2D, s->eps, s->min_pts, 0, nullptr, d_local,
-                            nullptr, nullptr, &cf, &ev, &ext));
-  }
+  unsigned long long* hb = reinterpret_cast<unsigned long long*>(ctx->pinned) + 128;
   if (pts_small > 0) {
-    hipLaunchKernelGGL(k_block_brute, dim3((unsigned)(hi - lo)), dim3(BRT), 0, ctx->stream, s->motor_bm.as<double>(),
-                       s->blockstart.as<uint32_t>(), (uint32_t)lo, thr, s->eps, s->min_pts, s->x_Min, s->y_Min, d_local, s->gtwice.as<uint32_t>(),
-                       s->gnclus.as<uint32_t>(), bc);
-    unsigned long long* hb = reinterpret_cast<unsigned long long*>(ctx->pinned) + 128;
-    VCP_HIP(ctx, hipMemcpyAsync(hb, bc, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    if (!s->side) {
+      VCP_HIP(ctx, hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+      VCP_HIP(ctx, hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+    }
+    VCP_TRY(ens(ctx, s->brutecnt, 128 * sizeof(unsigned long long)));
+    unsigned long long* bc = s->brutecnt.as<unsigned long long>();  // [64][2]: op counter, clusters of the small blocks
+    VCP_HIP(ctx, hipEventRecord(s->ev_fork, ctx->stream));
+    VCP_HIP(ctx, hipStreamWaitEvent(s->side, s->ev_fork, 0));
+    hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(BT), 0, s->side, reinterpret_cast<uint32_t*>(bc), 256u);
+    hipLaunchKernelGGL(k_block_brute<BRT>, dim3((unsigned)(hi - lo)), dim3(BRT), 0, s->side, s->motor_bm.as<double>(),
+                       s->blockstart.as<uint32_t>(), (uint32_t)lo, 0u, thr, s->eps, s->min_pts, s->x_Min, s->y_Min, d_local, bc);
+    if (thr > (uint32_t)BRT && any_mid)
+      hipLaunchKernelGGL(k_block_brute<BRUTE_CAP>, dim3((unsigned)(hi - lo)), dim3(BRT), 0, s->side,
+                         s->motor_bm.as<double>(), s->blockstart.as<uint32_t>(), (uint32_t)lo, (uint32_t)BRT, thr, s->eps,
+                         s->min_pts, s->x_Min, s->y_Min, d_local, bc);
+    VCP_HIP(ctx, hipMemcpyAsync(hb, bc, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->side));
     VCP_HIP(ctx, hipGetLastError());
-    VCP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (pts_big > 0) {
+    DbscanExt ext;
+    ext.d_group = thr > 0 ? s->grp_big.as<int32_t>()
+                          : reinterpret_cast<const int32_t*>(s->blk_t.as<uint32_t>());  // block id per block-major position
+    ext.skip_upto = thr;
+    ext.d_ord = nullptr;  // list position = input index
+    ext.d_groupstart = s->blockstart.as<uint32_t>();
+    ext.G = (int32_t)s->nblocks;
+    ext.only_lo = lo;
+    ext.only_hi = hi;
+    ext.d_group_twice = s->gtwice.as<uint32_t>();
+    ext.d_group_nclus = s->gnclus.as<uint32_t>();
+    const double bbox[6] = {s->mbox[0], s->mbox[2], 0.0, s->mbox[1], s->mbox[3], 0.0};  // the partition has seen every point
+    ext.h_bbox = bbox;
+    // input = the m points that fell in a block, in block-major order; positions outside [lo, hi)'s slice are left alone
+    const int rc = vcp_dbscan_engine(ctx, s->motor_bm.as<double>(), s->m, 2, VCP_L1_2D, s->eps, s->min_pts, 0, nullptr, d_local,
+                                     nullptr, nullptr, &cf, &ev, &ext);
+    if (rc != VCP_OK) {
+      if (pts_small > 0) (void)hipStreamSynchronize(s->side);
+      return rc;
+    }
+  }
+  VCP_HIP(ctx, hipGetLastError());
+  if (pts_small > 0) {
+    VCP_HIP(ctx, hipStreamSynchronize(s->side));
     for (int k = 0; k < 64; k++) {
       ev += (int64_t)hb[2 * k];
       cf += (int32_t)hb[2 * k + 1];
     }
-  } else {
-    VCP_HIP(ctx, hipGetLastError());
-    VCP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
+  VCP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (evals_o) *evals_o = ev;
   // the clusters of the blocks clustered so far (the finish stage sizes its arrays with it when every block is in)
   if (lo == s->cov_hi) {
@@ -855,7 +987,7 @@ int finish_local(vcp_ctx* ctx, const int32_t* d_local, bool sharded, bool force_
       hipLaunchKernelGGL(k_block_order<1>, dim3(nbw), dim3(BT), 0, st, d_local, blockstart, nb, kb, nullptr, cstart, csize,
                          order, dmisc + 4, b_lo);
       if (s->nbig)
-        hipLaunchKernelGGL(k_block_order<16>, dim3(s->nbig), dim3(1024), 0, st, d_local, blockstart, nb, kb,
+        hipLaunchKernelGGL(k_block_order_big, dim3(s->nbig), dim3(64 * OBW), 0, st, d_local, blockstart, kb,
                            s->biglist.as<uint32_t>(), cstart, csize, order, dmisc + 4, b_lo);
     } else if (m > 0) {
       VCP_TRY(ens(ctx, s->tmp0, (size_t)(m + 1) * 8));
@@ -913,10 +1045,11 @@ int finish_zero(vcp_ctx* ctx, bool sharded, int zero_last, bool* again) {
   if (again) *again = false;
   if (sharded && zero_last) hipLaunchKernelGGL(k_zero_one, dim3(1), dim3(1), 0, st, newlab, dmisc);
   // zero list (FrmMain.cs:1510-1515)
-  VCP_TRY(ens(ctx, s->zflag, (size_t)(m + 2) * 4));
-  VCP_TRY(ens(ctx, s->zlist, (size_t)(m + 2) * 4));
-  uint32_t* zflag = s->zflag.as<uint32_t>();
-  uint32_t* aflag = s->zlist.as<uint32_t>();
+  const int64_t nw = (m + 31) / 32;  // words of the two bitmaps; each buffer: [nw + 2] word counts, then [nw] words
+  VCP_TRY(ens(ctx, s->zflag, (size_t)(2 * nw + 4) * 4));
+  VCP_TRY(ens(ctx, s->zlist, (size_t)(2 * nw + 4) * 4));
+  uint32_t* zcnt = s->zflag.as<uint32_t>();
+  uint32_t* acnt = s->zlist.as<uint32_t>();
   BandP B;
   B.x_Min = s->x_Min;
   B.x_Max = s->x_Max;
@@ -930,10 +1063,10 @@ int finish_zero(vcp_ctx* ctx, bool sharded, int zero_last, bool* again) {
   B.r2 = 2.0 * s->eps * (1.0 + 1.0 / 1099511627776.0);
   static const bool band_off = getenv("VCP_NOISE_ALL") != nullptr;  // test switch: the whole zero list
   B.all_active = (s->d_key != s->d_motor || !(s->eps >= 0.0) || !std::isfinite(B.r2) || band_off) ? 1 : 0;
-  hipLaunchKernelGGL(k_zero_flag, dim3(nblk(m)), dim3(BT), 0, st, newlab, order, m, zflag, s->f_local, s->motor_bm.as<double>(),
-                     s->blk_t.as<uint32_t>(), B, aflag);
-  VCP_TRY(vcp_exclusive_scan_u32(ctx, zflag, zflag, m + 1, dmisc + 3));
-  VCP_TRY(vcp_exclusive_scan_u32(ctx, aflag, aflag, m + 1, dmisc + 9));
+  hipLaunchKernelGGL(k_zero_flag, dim3(nblk(m)), dim3(BT), 0, st, newlab, order, m, zcnt, zcnt + nw + 2, s->f_local,
+                     s->motor_bm.as<double>(), s->blk_t.as<uint32_t>(), B, acnt, acnt + nw + 2);
+  VCP_TRY(vcp_exclusive_scan_u32(ctx, zcnt, zcnt, nw + 1, dmisc + 3));
+  VCP_TRY(vcp_exclusive_scan_u32(ctx, acnt, acnt, nw + 1, dmisc + 9));
   VCP_HIP(ctx, hipMemcpyAsync(hp, dmisc, 48, hipMemcpyDeviceToHost, st));
   VCP_HIP(ctx, hipStreamSynchronize(st));
   if (!sharded) {
@@ -955,11 +1088,12 @@ int finish_zcoords(vcp_ctx* ctx, double* d_zcoords, int64_t* d_merge_order, int 
   BlocksState* s = ctx->blocks;
   hipStream_t st = ctx->stream;
   const int64_t m = s->m;
+  const int64_t nw = (m + 31) / 32;
   if (m > 0)
-    hipLaunchKernelGGL(k_compact, dim3(nblk(m)), dim3(BT), 0, st, s->zflag.as<uint32_t>(), s->newlab.as<int32_t>(),
+    hipLaunchKernelGGL(k_compact, dim3(nblk(m)), dim3(BT), 0, st, s->zflag.as<uint32_t>(), s->zflag.as<uint32_t>() + nw + 2,
                        s->order.as<uint32_t>(), s->bl.as<uint32_t>(), s->motor_bm.as<double>(), m, s->f_Z,
                        s->tmp2.as<uint32_t>() /* zrank: free again (it held the identity of the library-sort order) */,
-                       d_zcoords, d_merge_order, swap_xy, s->zlist.as<uint32_t>());
+                       d_zcoords, d_merge_order, swap_xy, s->zlist.as<uint32_t>(), s->zlist.as<uint32_t>() + nw + 2);
   VCP_HIP(ctx, hipGetLastError());
   return VCP_OK;
 }
@@ -1031,6 +1165,10 @@ void vcp_blocks_state_free(vcp_ctx* ctx) {
                    &s->vlist, &s->fall, &s->gcnt, &s->grp_big, &s->brutecnt};
   for (DevBuf* b : all)
     if (b->p) (void)hipFree(b->p);
+  if (s->side) {
+    (void)hipStreamDestroy(s->side);
+    (void)hipEventDestroy(s->ev_fork);
+  }
   delete s;
   ctx->blocks = nullptr;
 }

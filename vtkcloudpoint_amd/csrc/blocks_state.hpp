@@ -22,6 +22,8 @@ struct BlocksState {
   // grid engine, which reads grp_big [m]: the block id of a point of a larger block, -1 for the others (0 = engine only)
   uint32_t brute_thr = 0;
   DevBuf grp_big, brutecnt;
+  hipStream_t side = nullptr;  // the all-pairs kernels run here, beside the engine's launches on the context's stream
+  hipEvent_t ev_fork = nullptr;
   bool virt_clean = false;  // gcnt is all zero
   // the plan (identical on every rank) ...
   bool planned = false, built = false;

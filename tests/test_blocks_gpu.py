@@ -253,3 +253,39 @@ def test_millions_of_blocks(vcp_ctx, oracle):
     motor = np.concatenate([motor, dense])
     o = _check(vcp_ctx, oracle, motor, 0.05, 4, 4, "tiny first block")
     assert o["rows"] * o["cols"] > 4_500_000
+
+
+def test_small_blocks_all_pairs_kernel(vcp_ctx, oracle):
+    """Blocks of up to 1024 points are clustered by the all-pairs kernel (blocks.hip: k_block_brute) with a candidate window
+    from the in-block order of d: both size classes (<= 256, <= 1024 points), blocks with several clusters, border points
+    between two clusters, pairs at distance exactly eps (lattice coordinates), duplicates (equal d), large coordinate offsets
+    (the window's rounding slack), minPts 1 (every point core) and a minPts nobody reaches."""
+    rng = np.random.default_rng(21)
+    seen_mid = seen_clusters = 0
+    for trial in range(40):
+        nblob = int(rng.integers(5, 60))
+        cen = rng.random((nblob, 2)) * 30.0
+        pts = [cen[i] + rng.normal(0.0, 0.15, size=(int(rng.integers(5, 60)), 2)) for i in range(nblob)]
+        pts.append(rng.random((int(rng.integers(200, 1500)), 2)) * 30.0)
+        motor = np.concatenate(pts)
+        if trial % 3 == 0:
+            motor = np.round(motor * 4.0) / 4.0          # lattice: ties at exactly eps, duplicates
+        if trial % 5 == 1:
+            motor += np.array([3.0e8, -7.0e8])           # large offsets: coarse spacing of the doubles
+        if trial % 7 == 2:
+            motor = np.concatenate([motor, np.repeat(motor[:40], 6, axis=0)])   # heaps of identical points
+        motor = motor[rng.permutation(len(motor))]
+        eps = float(rng.choice([0.25, 0.3, 0.5]))
+        mp = int(rng.choice([1, 3, 4, 6, 2000]))
+        pic = int(rng.choice([100, 250, 300, 600, 1000]))
+        try:
+            o = _check(vcp_ctx, oracle, motor, eps, mp, pic, "all-pairs trial %d" % trial)
+        except oracle.OracleError as e:   # the reference's index -1 while demoting the first cluster (FrmMain.cs:1487)
+            with pytest.raises(N.VcpError) as ge:
+                vcp_ctx.dbscan_blocks(np.ascontiguousarray(motor), eps, mp, pic, 3)
+            assert ge.value.code == e.code
+            continue
+        counts = np.bincount(o["block_of"][o["block_of"] >= 0])
+        seen_mid += int(((counts > 256) & (counts <= 1024)).any())
+        seen_clusters += int(o["kept"] > 3)
+    assert seen_mid > 5 and seen_clusters > 10

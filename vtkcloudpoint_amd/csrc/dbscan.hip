@@ -1907,7 +1907,9 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
     VCP_TRY(vcp_ensure(ctx, ctx->b_nboff, (size_t)nb * TPB * 2));
     no.nbr = ctx->b_nbr.as<uint32_t>();
     no.off = ctx->b_nboff.as<uint16_t>();
+    static const int cap_env = getenv("VCP_CORE_CAP") ? atoi(getenv("VCP_CORE_CAP")) : -1;  // test switch
     no.core_cap = (GD == 2 && (uint64_t)n < (uint64_t)g.ncells) ? std::min(no.NB, CORE_LIST) : no.NB;
+    if (cap_env >= 0) no.core_cap = std::min(no.NB, cap_env);
   }
   const size_t lds_nb = (size_t)no.NB * TPB * 4;
   if constexpr (GD == 2 && !GROUPED)

@@ -633,13 +633,19 @@ __device__ __forceinline__ bool tile_bounds(CoreTile<GD>& t, bool live, const in
   return fits;
 }
 
+// tg / sgroup: grouped calls stage the candidates' group ids beside their coordinates
 template <int GD>
-__device__ __forceinline__ void tile_load(CoreTile<GD>& t, const float* __restrict__ sorted32) {
+__device__ __forceinline__ void tile_load(CoreTile<GD>& t, const float* __restrict__ sorted32,
+                                          int32_t (*tg)[CoreTile<GD>::CAP + 4] = nullptr,
+                                          const int32_t* __restrict__ sgroup = nullptr) {
 #pragma unroll
   for (int r = 0; r < CoreTile<GD>::NR; r++) {
     const uint32_t lo = t.lo[r], hi = t.hi[r];
     if (hi > lo)
-      for (uint32_t k = threadIdx.x; k < hi - lo; k += TPB) t.put(r, k, sorted32, lo + k);
+      for (uint32_t k = threadIdx.x; k < hi - lo; k += TPB) {
+        t.put(r, k, sorted32, lo + k);
+        if (tg) tg[r][k] = sgroup[lo + k];
+      }
   }
   __syncthreads();
 }
@@ -651,7 +657,8 @@ __device__ __forceinline__ void tile_load(CoreTile<GD>& t, const float* __restri
 template <int GD, int METRIC>
 __device__ __forceinline__ void nbr_flush_masks(const NbrOut& no, uint32_t* lout, const uint32_t* hm, const uint32_t* rs,
                                                 const uint32_t* re, bool rescan, int nrec, double thr, const ExactSrc& xs,
-                                                int64_t blk, int64_t p, bool live) {
+                                                int64_t blk, int64_t p, bool live,
+                                                const int32_t* __restrict__ sgroup = nullptr) {
   if (no.NB == 0) return;
   constexpr int NR = CoreTile<GD>::NR;
   __shared__ uint32_t wtot[TPB / 64];
@@ -675,7 +682,7 @@ __device__ __forceinline__ void nbr_flush_masks(const NbrOut& no, uint32_t* lout
       for (uint32_t j = rs[r]; j < re[r] && k < nrec; j++) {
         double rr[3];
         load_exact<GD>(xs, j, rr);
-        if (j != (uint32_t)p && within<METRIC>(q, rr, thr)) lout[pre + (k++)] = j;
+        if (j != (uint32_t)p && within<METRIC>(q, rr, thr) && (!sgroup || sgroup[j] == sgroup[p])) lout[pre + (k++)] = j;
       }
   } else {
 #pragma unroll
@@ -693,24 +700,27 @@ __device__ __forceinline__ void nbr_flush_masks(const NbrOut& no, uint32_t* lout
   for (uint32_t i = threadIdx.x; i < total; i += TPB) dst[i] = lout[i];
 }
 
-template <int GD, int METRIC>
+template <int GD, int METRIC, bool GROUPED = false>
 __global__ __launch_bounds__(TPB) void k_core_lds(ExactSrc xs, GridP g, double thr, int min_pts,
-                                                 CellTab ct, uint8_t* __restrict__ flags,
+                                                 CellTab ct, const int32_t* __restrict__ sgroup, uint8_t* __restrict__ flags,
                                                  uint32_t* __restrict__ parent, uint32_t* __restrict__ minord,
                                                  uint32_t* __restrict__ blkE, uint32_t* __restrict__ blkB, NbrOut no,
                                                  const float* __restrict__ sorted32, Screen sc, bool has_cls) {
   constexpr int NR = CoreTile<GD>::NR;
   constexpr int OWN = NR / 2;  // the row of the point's own cell (dy = dz = 0)
   __shared__ CoreTile<GD> t;
+  __shared__ int32_t tg[GROUPED ? NR : 1][CoreTile<GD>::CAP + 4];  // grouped calls: the candidates' groups
   const uint32_t nin = *ct.nin;
   const int64_t blk = xcd_block(gridDim.x);
   int64_t p = blk * TPB + threadIdx.x;
   const bool live = p < nin;
   int cc[3] = {0, 0, 0};
   float qf[3] = {0.f, 0.f, 0.f};
+  int32_t myg = 0;
   if (live) {
     load_pt32<GD>(sorted32, p, qf);
     cell_of32<GD>(qf, g, cc);
+    if (GROUPED) myg = sgroup[p];
   }
   uint32_t rs[NR], re[NR];
   const bool fits = tile_bounds<GD>(t, live, cc, g, ct, rs, re);
@@ -726,7 +736,8 @@ __global__ __launch_bounds__(TPB) void k_core_lds(ExactSrc xs, GridP g, double t
 #pragma unroll
   for (int r = 0; r < NR; r++) hm[r] = 0u;
   if (fits) {
-    tile_load<GD>(t, sorted32);
+    if constexpr (GROUPED) tile_load<GD>(t, sorted32, tg, sgroup);
+    else tile_load<GD>(t, sorted32);
     if (live) {
 #pragma unroll
       for (int k = 0; k < NR; k++) {
@@ -750,6 +761,7 @@ __global__ __launch_bounds__(TPB) void k_core_lds(ExactSrc xs, GridP g, double t
 #pragma unroll
           for (int u = UNR - 1; u >= 0; u--) {
             w[u] = __float_as_uint(value32<METRIC>(qf, c[u])) - scLO;
+            if (GROUPED) w[u] = tg[r][j + u] == myg ? w[u] : scS;  // another group's point: outside, and decided
             nib = __builtin_amdgcn_alignbit(nib, w[u] - scS, 31);
           }
           nib &= 0xFu >> (4u - min(e - j, 4u));  // candidates past the lane's range
@@ -785,7 +797,8 @@ __global__ __launch_bounds__(TPB) void k_core_lds(ExactSrc xs, GridP g, double t
         uint32_t nib = 0;
 #pragma unroll
         for (int u = 0; u < UNR; u++)
-          nib |= ((j + u < re[r]) && within_scr<GD, METRIC>(qf, rr[u], sc, xs, (uint32_t)p, j + u, thr)) ? (1u << u) : 0u;
+          nib |= ((j + u < re[r]) && (!GROUPED || sgroup[j + u] == myg) &&
+                  within_scr<GD, METRIC>(qf, rr[u], sc, xs, (uint32_t)p, j + u, thr)) ? (1u << u) : 0u;
         cnt += __popc(nib);
         const uint32_t sh = j - rs[r];
         hm[r] |= sh < 32u ? nib << sh : 0u;
@@ -831,7 +844,7 @@ __global__ __launch_bounds__(TPB) void k_core_lds(ExactSrc xs, GridP g, double t
     parent[p] = isE ? (uint32_t)p : NONE;
     if (isE) minord[p] = NONE;  // (read at roots only, and a root is an expanding point)
   }
-  nbr_flush_masks<GD, METRIC>(no, t.lout, hm, rs, re, rescan, nrec, thr, xs, blk, p, live);
+  nbr_flush_masks<GD, METRIC>(no, t.lout, hm, rs, re, rescan, nrec, thr, xs, blk, p, live, GROUPED ? sgroup : nullptr);
   wl_count(isE, isB, (uint32_t)blk, blkE, blkB);
 }
 
@@ -1912,10 +1925,15 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
     if (cap_env >= 0) no.core_cap = std::min(no.NB, cap_env);
   }
   const size_t lds_nb = (size_t)no.NB * TPB * 4;
-  if constexpr (GD == 2 && !GROUPED)
-    hipLaunchKernelGGL((k_core_lds<GD, METRIC>), dim3(nb), dim3(TPB), 0, st, xs, g, thr, min_pts, ct, flags, parent,
-                       minord, blkE, blkB, no, sorted32, sc, flags_set);
-  else
+  static const bool core_global = getenv("VCP_CORE_GLOBAL") != nullptr;  // test switch: grouped calls through k_core
+  if constexpr (GD == 2) {
+    if (!GROUPED || !core_global)
+      hipLaunchKernelGGL((k_core_lds<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 0, st, xs, g, thr, min_pts, ct, sgroup, flags,
+                         parent, minord, blkE, blkB, no, sorted32, sc, flags_set);
+    else
+      hipLaunchKernelGGL((k_core<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 2 * lds_nb, st, xs, g, thr, min_pts, ct,
+                         sgroup, flags, parent, minord, blkE, blkB, no, sorted32, sc, flags_set);
+  } else
     hipLaunchKernelGGL((k_core<GD, METRIC, GROUPED>), dim3(nb), dim3(TPB), 2 * lds_nb, st, xs, g, thr, min_pts, ct,
                        sgroup, flags, parent, minord, blkE, blkB, no, sorted32, sc, flags_set);
   // ONE scan over both count arrays (they are adjacent): the B half comes out offset by everything before it, which

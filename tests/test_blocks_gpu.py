@@ -289,3 +289,19 @@ def test_small_blocks_all_pairs_kernel(vcp_ctx, oracle):
         seen_mid += int(((counts > 256) & (counts <= 1024)).any())
         seen_clusters += int(o["kept"] > 3)
     assert seen_mid > 5 and seen_clusters > 10
+
+
+def test_tens_of_millions_of_blocks(vcp_ctx, oracle):
+    """More than 2^25 blocks (a first block of 0.1 x 0.024 units on a 300 x 300 cloud): a launch of one workgroup per block
+    would hold more than 2^32 threads -- the per-block kernels walk the blocks with a capped grid.  (Found by the fuzz sweep,
+    seed 41: the wrapped launch left most blocks unclustered.)"""
+    rng = np.random.default_rng(14)
+    n = 60_000
+    motor = np.round(rng.random((n, 2)) * 300.0 * 1024) / 1024
+    motor[motor[:, 0] < 1.0, 0] += 1.0      # keep the band along both minimum edges clear ...
+    motor[motor[:, 1] < 1.0, 1] += 1.0
+    motor[0] = (0.0, 150.0)                 # ... so that x_Min, y_Min come from two different points
+    motor[1] = (150.0, 0.0)
+    motor[2] = (0.1, 0.0234375)             # the point of smallest d: the first block, 0.1 x 0.0234375
+    o = _check(vcp_ctx, oracle, motor, 1.2, 7, 1, "37 M blocks")
+    assert o["rows"] * o["cols"] > 35_000_000

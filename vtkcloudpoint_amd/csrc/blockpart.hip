@@ -761,7 +761,10 @@ __global__ __launch_bounds__(BIG ? 1024 : 128) void k_blk_sort(const Rec32* __re
                                                                KeyPart* __restrict__ stage_g, uint32_t* __restrict__ rk_g,
                                                                double* __restrict__ motor_bm, uint32_t* __restrict__ bl,
                                                                uint32_t* __restrict__ blk_t, uint32_t b_lo, int has_dropped,
-                                                               int32_t* __restrict__ grp_big, uint32_t brute_thr) {
+                                                               int32_t* __restrict__ grp_big, uint32_t brute_thr,
+                                                               uint32_t nshare) {
+  // nshare (LIST = BIG = false): blocks of the share; the grid is capped and walks them (a launch of one workgroup per
+  // block wraps at 2^32 threads: 33 M blocks)
   constexpr int NT = BIG ? 1024 : 128;
   constexpr uint32_t SBMAX = BIG ? 8192u : 512u;
   constexpr uint32_t PER = SBMAX / NT;
@@ -775,8 +778,8 @@ __global__ __launch_bounds__(BIG ? 1024 : 128) void k_blk_sort(const Rec32* __re
     const uint32_t s = blockstart[nblocks], e = blockstart[nblocks + 1];
     for (uint32_t j = s + blockIdx.x * NT + threadIdx.x; j < e; j += gridDim.x * NT) bl[j] = rec2[j].idx;
   }
-  const uint32_t nlist = BIG ? st->nfall : LIST ? st->nvirt : 1u;
-  for (uint32_t q = LIST || BIG ? blockIdx.x : 0u; q < nlist; q += gridDim.x) {
+  const uint32_t nlist = BIG ? st->nfall : LIST ? st->nvirt : nshare;
+  for (uint32_t q = blockIdx.x; q < nlist; q += gridDim.x) {
     uint32_t b, s, e;
     const Rec32* src = rec2;
     if (BIG || LIST) {
@@ -793,10 +796,10 @@ __global__ __launch_bounds__(BIG ? 1024 : 128) void k_blk_sort(const Rec32* __re
         if (e - s > VCP_BIG_BLOCK || e == s) continue;  // (uniform over the workgroup)
       }
     } else {
-      b = b_lo + blockIdx.x;
+      b = b_lo + q;
       s = blockstart[b];
       e = blockstart[b + 1];
-      if (e == s || e - s > VCP_BIG_BLOCK) return;
+      if (e == s || e - s > VCP_BIG_BLOCK) continue;  // (uniform over the workgroup)
     }
     const uint32_t m = e - s;
     // what the grid engine reads as the point's group: the points of blocks small enough for the all-pairs kernel are not its
@@ -1074,7 +1077,8 @@ int vcp_blocks_plan(vcp_ctx* ctx, BlocksState* s, const double* d_key, const dou
   s->rows = (int)fr + 1;
   s->cols = (int)fc + 1;
   s->nblocks = (int64_t)s->rows * s->cols;
-  if (s->nblocks > ((int64_t)1 << 26)) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "%lld blocks", (long long)s->nblocks);
+  // (2^26 - 4: the kernels with a wave per block launch nblocks * 64 threads, and a launch holds fewer than 2^32)
+  if (s->nblocks > ((int64_t)1 << 26) - 4) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "%lld blocks", (long long)s->nblocks);
 
   // block of every point (FrmMain.cs:1259-1285, Tools.cs:510-513) and the population of every super-bucket
   const PartP P{s->x_Min, s->x_Max, s->y_Min, s->y_Max, s->cell_x, s->cell_y, 1.0 / s->cell_x, 1.0 / s->cell_y, s->rows, s->cols};
@@ -1178,9 +1182,10 @@ int vcp_blocks_build(vcp_ctx* ctx, BlocksState* s, uint32_t S_lo, uint32_t S_hi,
                        S_lo, S_hi, off0);
 #define VCP_SORT_ARGS(list) rec2, rec, blockstart, nblocks, list, d_sel, fall, gcnt, s->stage.as<KeyPart>(),              \
                             s->rank.as<uint32_t>(), s->motor_bm.as<double>(), s->bl.as<uint32_t>(), s->blk_t.as<uint32_t>(), \
-                            b_lo, has_dropped ? 1 : 0, s->brute_thr ? s->grp_big.as<int32_t>() : nullptr, s->brute_thr
+                            b_lo, has_dropped ? 1 : 0, s->brute_thr ? s->grp_big.as<int32_t>() : nullptr, s->brute_thr, \
+                            (uint32_t)(s->b_hi - s->b_lo)
     if (s->b_hi > s->b_lo)
-      hipLaunchKernelGGL((k_blk_sort<false, false>), dim3(nbl), dim3(128), 0, st, VCP_SORT_ARGS(nullptr));
+      hipLaunchKernelGGL((k_blk_sort<false, false>), dim3(std::min(nbl, 1u << 22)), dim3(128), 0, st, VCP_SORT_ARGS(nullptr));
     const unsigned gsl = (unsigned)std::min<size_t>(2048, nbig_cap + nl / SLICE);
     hipLaunchKernelGGL(k_big_count, dim3(gsl), dim3(PT), 0, st, rec2, s->binfo.as<BigInfo>(), s->slicelist.as<uint2>(), d_sel,
                        gcnt);

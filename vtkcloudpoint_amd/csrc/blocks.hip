@@ -675,11 +675,10 @@ __device__ __forceinline__ BruteWin brute_window(const double2* pt, uint32_t ng,
 // CAP = points of LDS: blocks of (above, CAP'] points, CAP' = min(CAP, thr_small).  Two instances: most blocks hold a few
 // hundred points and their workgroups should not reserve the LDS of the largest (6 KB against 24: eight workgroups per CU)
 template <uint32_t CAP>
-__global__ __launch_bounds__(BRT) void k_block_brute(const double* __restrict__ motor_bm, const uint32_t* __restrict__ blockstart,
-                                                    uint32_t lo, uint32_t above, uint32_t thr_small, double eps, int min_pts, double x_Min,
-                                                    double y_Min, int32_t* __restrict__ d_local,
-                                                    unsigned long long* __restrict__ counters) {
-  const uint32_t b = lo + blockIdx.x;
+__device__ __forceinline__ void brute_block(const uint32_t b, const double* __restrict__ motor_bm,
+                                            const uint32_t* __restrict__ blockstart, uint32_t above, uint32_t thr_small, double eps,
+                                            int min_pts, double x_Min, double y_Min, int32_t* __restrict__ d_local,
+                                            unsigned long long* __restrict__ counters) {
   const uint32_t s0 = blockstart[b], ng = blockstart[b + 1] - s0;
   constexpr int BRP = (int)(CAP / BRT);  // points per thread
   if (ng > thr_small || ng > CAP || (above > 0u && ng <= above)) return;
@@ -836,6 +835,17 @@ __global__ __launch_bounds__(BRT) void k_block_brute(const double* __restrict__ 
     atomicAdd(&counters[2 * (b & 63u) + 1], (unsigned long long)kg);
   }
 }
+// blocks [lo, hi): the grid is capped and walks them (one workgroup per block would wrap at 2^32 threads: 16 M blocks)
+template <uint32_t CAP>
+__global__ __launch_bounds__(BRT) void k_block_brute(const double* __restrict__ motor_bm, const uint32_t* __restrict__ blockstart,
+                                                    uint32_t lo, uint32_t hi, uint32_t above, uint32_t thr_small, double eps,
+                                                    int min_pts, double x_Min, double y_Min, int32_t* __restrict__ d_local,
+                                                    unsigned long long* __restrict__ counters) {
+  for (uint32_t b = lo + blockIdx.x; b < hi; b += gridDim.x) {
+    brute_block<CAP>(b, motor_bm, blockstart, above, thr_small, eps, min_pts, x_Min, y_Min, d_local, counters);
+    __syncthreads();  // the LDS arrays are the next block's
+  }
+}
 
 int blocks_cluster(vcp_ctx* ctx, int32_t lo, int32_t hi, int32_t* d_local, int64_t* evals_o) {
   BlocksState* s = ctx->blocks;
@@ -876,12 +886,14 @@ int blocks_cluster(vcp_ctx* ctx, int32_t lo, int32_t hi, int32_t* d_local, int64
     VCP_HIP(ctx, hipEventRecord(s->ev_fork, ctx->stream));
     VCP_HIP(ctx, hipStreamWaitEvent(s->side, s->ev_fork, 0));
     hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(BT), 0, s->side, reinterpret_cast<uint32_t*>(bc), 256u);
-    hipLaunchKernelGGL(k_block_brute<BRT>, dim3((unsigned)(hi - lo)), dim3(BRT), 0, s->side, s->motor_bm.as<double>(),
-                       s->blockstart.as<uint32_t>(), (uint32_t)lo, 0u, thr, s->eps, s->min_pts, s->x_Min, s->y_Min, d_local, bc);
+    const unsigned gb = (unsigned)std::min<int64_t>((int64_t)hi - lo, (int64_t)1 << 22);
+    hipLaunchKernelGGL(k_block_brute<BRT>, dim3(gb), dim3(BRT), 0, s->side, s->motor_bm.as<double>(),
+                       s->blockstart.as<uint32_t>(), (uint32_t)lo, (uint32_t)hi, 0u, thr, s->eps, s->min_pts, s->x_Min, s->y_Min,
+                       d_local, bc);
     if (thr > (uint32_t)BRT && any_mid)
-      hipLaunchKernelGGL(k_block_brute<BRUTE_CAP>, dim3((unsigned)(hi - lo)), dim3(BRT), 0, s->side,
-                         s->motor_bm.as<double>(), s->blockstart.as<uint32_t>(), (uint32_t)lo, (uint32_t)BRT, thr, s->eps,
-                         s->min_pts, s->x_Min, s->y_Min, d_local, bc);
+      hipLaunchKernelGGL(k_block_brute<BRUTE_CAP>, dim3(gb), dim3(BRT), 0, s->side, s->motor_bm.as<double>(),
+                         s->blockstart.as<uint32_t>(), (uint32_t)lo, (uint32_t)hi, (uint32_t)BRT, thr, s->eps, s->min_pts,
+                         s->x_Min, s->y_Min, d_local, bc);
     VCP_HIP(ctx, hipMemcpyAsync(hb, bc, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->side));
     VCP_HIP(ctx, hipGetLastError());
   }

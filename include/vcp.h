@@ -133,7 +133,9 @@ int vcp_dbscan_dev(vcp_ctx* ctx, const double* d_coords, int64_t n, int dim, int
  * motor [n*2]; labels [n] by original index (0 = noise or dropped); block_of [n] may be NULL
  * (-1 = in no block); merge_order [n] may be NULL: original indices in final clusForMerge
  * order, *m_out entries.  kept = clusters surviving the demotion, del_sum = demoted clusters,
- * cluster_amount = DBImproved.clusterAmount after the noise pass (FrmMain.cs:1521-1522). */
+ * cluster_amount = DBImproved.clusterAmount after the noise pass (FrmMain.cs:1521-1522).
+ * Limits: rows * cols <= 2^26 - 4 blocks (VCP_ERR_TOO_LARGE beyond: the C#'s cells[,] would be a 4 GB array of list
+ * references there); a first block of zero extent = VCP_ERR_DEGENERATE (the C# divides by it, :1256-1259). */
 int vcp_dbscan_blocks(vcp_ctx* ctx, const double* motor, int64_t n, double eps, int min_pts,
                       int pts_in_cell, int small_max, int32_t* labels, int32_t* block_of,
                       int64_t* merge_order, int64_t* m_out, int32_t* rows, int32_t* cols,

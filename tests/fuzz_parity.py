@@ -248,7 +248,7 @@ def run(budget=300.0, seed=12345, max_log_n=6.3, gpu_bound=None, device=0, quiet
             try:
                 gb = ctx.dbscan_blocks(m2, eps, mp, pic, 3)
             except N.VcpError as e:
-                if e.code == -5:  # more than 2^26 blocks: the library's documented limit (the C# would need a 4 GB array)
+                if e.code == -5:  # more than 2^26 - 4 blocks: the library's documented limit (the C# would need a 4 GB array)
                     continue
                 raise
             okb = (np.array_equal(gb["labels"], ob["labels"]) and np.array_equal(gb["order"], ob["order"])

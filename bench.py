@@ -398,11 +398,11 @@ def main():
             record([("finish:" + nm, ms) for nm, ms in ctx.timing()])
             del loc1, lab1
         if dist and world > 1:
-            collectives.append({"op": "all_gather of 9 int64 per rank (cluster counts, quirk flags, op counters, sizes)",
+            collectives.append({"op": "all_gather of 10 int64 per rank (cluster counts, quirk flags, op counters, sizes)",
                                 "backend": "nccl (RCCL)", "per_step": 1})
-            collectives.append({"op": "all_gather (sizes, then data) of the active noise points' coordinates: 16 B per "
-                                      "point the global noise pass can reach (an eighth of the zero list); the pass itself "
-                                      "runs on every rank", "backend": "nccl (RCCL)", "per_step": 2,
+            collectives.append({"op": "all_gather (sizes known from the first exchange) of the active noise points' "
+                                      "coordinates: 16 B per point the global noise pass can reach (an eighth of the zero "
+                                      "list); the pass itself runs on every rank", "backend": "nccl (RCCL)", "per_step": 1,
                                 "active_noise_points": last.get("noise_active")})
             collectives.append({"op": "all_gather_into_tensor((index, label) int64 pairs, padded to the largest share)",
                                 "backend": "nccl (RCCL)", "bytes_sent_per_rank_per_step": last["collective_bytes"],

@@ -455,8 +455,9 @@ def _pipeline_steps(backend, d_motor, n, eps, min_pts, pts_in_cell, small_max, r
     Every rank reads the whole cloud (device pointer d_motor, n points) but repeats only the streaming passes that decide
     the partition (bounds, first block, block of every point: MainForm.getClusterFromMotor, FrmMain.cs:1214-1258); it
     then builds, clusters (StartCode :2782-2794) and merges (CompleteWork3 :1442-1504) its own share of the blocks.
-    Exchanges: (1) nine words per rank -- cluster counts for the global renumbering (:1460-1504), who asks whom to zero a
-    last entry (the clusLen quirk :1461-1465 / :1485-1488 across a share boundary), op counters, sizes; (2) the global
+    Exchanges: (1) ten words per rank -- cluster counts for the global renumbering (:1460-1504), who asks whom to zero a
+    last entry (the clusLen quirk :1461-1465 / :1485-1488 across a share boundary), op counters, sizes (also of the
+    zero list's active part, so that no exchange needs a size exchange in front of it: three collectives per step); (2) the global
     noise pass (:1507-1516) over the ACTIVE points of the ranks' zero lists (the eighth of the noise a cluster of that pass
     can reach, csrc/blocks.hip: k_zero_flag) -- noise="gather": ONE all-gather of their coordinates (16 bytes per active
     point) and the pass itself on every rank (0.3 ms at 10 M points: cheaper than any exchange pattern); noise="slabs":
@@ -471,8 +472,11 @@ def _pipeline_steps(backend, d_motor, n, eps, min_pts, pts_in_cell, small_max, r
     local = torch.empty(max(m, 1), dtype=torch.int32, device=device)  # (every position of the share is written)
     evals = backend.blocks_cluster_dev(sh["block_lo"], sh["block_hi"], local.data_ptr()) if m > 0 else 0
     st = backend.blocks_finish_local(local.data_ptr())
+    # the zero list as it stands (nobody has asked this share to zero its last entry yet): its sizes travel with the counters,
+    # so that the exchange of the active points needs no size exchange of its own
+    z_all, z = backend.blocks_finish_zero(False)
     mine = torch.tensor([[st["clusters"], st["kept"], st["err"], st["req"], st["nonempty"], st["last_nonzero"], evals, m,
-                          n_loc]], dtype=i64, device=device)
+                          n_loc, z]], dtype=i64, device=device)
     allst = torch.cat((yield mine, True), dim=0).cpu().numpy().astype(np.int64)
     if int(allst[:, 2].sum()) != 0:
         raise IndexError("clusForMerge index -1 while demoting the first cluster (FrmMain.cs:1487)")
@@ -488,17 +492,23 @@ def _pipeline_steps(backend, d_motor, n, eps, min_pts, pts_in_cell, small_max, r
     kept_all = allst[:, 1]
     kept_off, kept_total = int(kept_all[:rank].sum()), int(kept_all.sum())
     clusters_total = int(allst[:, 0].sum())
-    z_all, z = backend.blocks_finish_zero(zero_me)  # the share's zero list, and the part of it the noise pass can reach
+    z_sent = z
+    if zero_me:  # (rare) the entry zeroed joins the zero list and its active part: one point more
+        z_all, z = backend.blocks_finish_zero(True)
     if noise == "gather":
-        # header row (zero-list size, active points) + the active points' coordinates, every rank's to every rank
-        zc = torch.empty((z + 1, 2), dtype=torch.float64, device=device)
+        # header row (zero-list size, active points) + the active points' coordinates, every rank's to every rank; row
+        # counts known from the first exchange (+ the header, + one row in case a last entry was zeroed since)
+        zc = torch.empty((z_sent + 2, 2), dtype=torch.float64, device=device)  # (rows behind the active points: never read)
         backend.blocks_finish_zcoords(zc[1:].data_ptr(), False)
         zc[0, 0] = float(z_all)
         zc[0, 1] = float(z)
-        allz = yield zc, False
-        z_total = int(round(sum(float(t[0, 0]) for t in allz)))
-        a_off = sum(int(t.shape[0]) - 1 for t in allz[:rank])
-        coords = torch.cat([t[1:] for t in allz], dim=0).contiguous() if world > 1 else zc[1:]
+        allz = yield zc, [int(c) + 2 for c in allst[:, 9]]
+        # one read-back: every rank's (zero list, active points)
+        heads = torch.stack([t[0] for t in allz]).cpu().numpy() if world > 1 else np.array([[float(z_all), float(z)]])
+        z_total = int(round(float(heads[:, 0].sum())))
+        acts = [int(round(float(v))) for v in heads[:, 1]]
+        a_off = sum(acts[:rank])
+        coords = torch.cat([t[1:1 + a] for t, a in zip(allz, acts)], dim=0).contiguous() if world > 1 else zc[1:1 + z]
         a_total = int(coords.shape[0])
         zlab_all = torch.empty(max(a_total, 1), dtype=torch.int32, device=device)
         cf, ev = kept_total, 0

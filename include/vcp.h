@@ -102,10 +102,11 @@ int vcp_timing_get(vcp_ctx* ctx, int i, const char** name, float* ms);
  * cf_in      DBImproved.cf before the call (FrmMain.cs:1509 presets it)
  * in_mask    ifShown filter of BC/DB.cs:40,63,98 -- only with VCP_SIGNED_SUM_2D, the dead v1.0 class DB
  *            (BC/DB.cs:14-115, FrmMain.cs:38): signed distance dx + dy on (x, y), clusters numbered from cf_in + 1,
- *            dist_evals = DB.iritatorNum, DB.pointsAmount = the number of shown points.  That class needs eps >= 0
- *            and finite coordinates, and coordinates for which its floating-point relation is provably the 1-D
- *            relation on x + y (a common binary grid, or no pair within rounding of the threshold); otherwise
- *            VCP_ERR_UNSUPPORTED (csrc/dbdead.hip)
+ *            dist_evals = DB.iritatorNum, DB.pointsAmount = the number of shown points.  Sorts and scans where the
+ *            class's floating-point relation is provably the 1-D relation on x + y (eps >= 0, finite coordinates, a
+ *            common binary grid or no pair within rounding of the threshold: csrc/dbdead.hip); every other input --
+ *            eps < 0 or NaN, non-finite coordinates included -- pair by pair, O(n^2), up to 2^21 points
+ *            (csrc/dbpairs.hip; VCP_ERR_UNSUPPORTED beyond)
  * in_classed NULL = nobody classed and labels start at 0 (what every caller sets up,
  *            FrmMain.cs:1219-1223, :1512-1515); else Point3D.isClassed on entry and `labels`
  *            is read as Point3D.clusterId on entry

@@ -114,15 +114,43 @@ def test_dead_class_DB_on_the_gpu(vcp_ctx, oracle):
     o = oracle.db_literal(c, 0.37, 4)
     g = vcp_ctx.dbscan(c, 0.37, 4, N.SIGNED_SUM_2D)
     assert np.array_equal(g["labels"], o["labels"]) and g["cf"] == o["cluster_amount"] and g["evals"] == o["evals"]
-    # ... refused when one does and the coordinates share no binary grid; e < 0 and non-finite points are refused too
-    c = np.array([[0.1, 0.2], [0.1 + 0.3, 0.2], [5.0, 1.0 / 3.0]])
-    with pytest.raises(N.VcpError) as e:
-        vcp_ctx.dbscan(c, 0.3, 1, N.SIGNED_SUM_2D)
-    assert e.value.code == -8
-    for bad_c, bad_eps in ((np.zeros((4, 2)), -0.5), (np.array([[0.0, np.nan], [1.0, 1.0]]), 0.5)):
-        with pytest.raises(N.VcpError) as e:
-            vcp_ctx.dbscan(bad_c, bad_eps, 2, N.SIGNED_SUM_2D)
-        assert e.value.code == -8
+    # ... and pair by pair (csrc/dbpairs.hip) when one does and the coordinates share no binary grid, for e < 0 / NaN and
+    # for non-finite coordinates: the C#'s expression on every pair, whatever it means geometrically
+    def same(c, eps, mp, shown=None, cls=None, lab0=None, what=""):
+        o = oracle.db_literal(c, eps, mp, shown, cls, lab0)
+        g = vcp_ctx.dbscan(c, eps, mp, N.SIGNED_SUM_2D, 0, cls, lab0, in_mask=shown)
+        assert np.array_equal(g["labels"], o["labels"]), what
+        assert np.array_equal(g["is_classed"], o["classed"]), what
+        assert np.array_equal(g["is_core"], o["is_key"]), what
+        assert g["cf"] == o["cluster_amount"] and g["evals"] == o["evals"], what
+
+    same(np.array([[0.1, 0.2], [0.1 + 0.3, 0.2], [5.0, 1.0 / 3.0]]), 0.3, 1, what="pair within rounding of the threshold")
+    same(np.zeros((4, 2)), -0.5, 2, what="e < 0: nobody is its own neighbour")
+    same(np.array([[0.0, np.nan], [1.0, 1.0]]), 0.5, 2, what="NaN coordinate")
+    for t in range(300):
+        n = int(rng.integers(1, 150))
+        kind = t % 4
+        if kind == 0:    # thirds: no binary grid, ties within rounding of the threshold
+            c = rng.integers(-12, 12, size=(n, 2)).astype(np.float64) / 3.0
+            eps = float(rng.choice([1.0 / 3.0, 2.0 / 3.0, 1.0, 0.1 + 0.2]))
+        elif kind == 1:  # e < 0 or NaN
+            c = rng.integers(-8, 8, size=(n, 2)).astype(np.float64) * 0.5
+            eps = float(rng.choice([-0.5, -2.0, -1e-300, np.nan]))
+        elif kind == 2:  # non-finite coordinates
+            c = rng.integers(-8, 8, size=(n, 2)).astype(np.float64) * 0.5
+            bad = rng.integers(0, n, max(1, n // 10))
+            c[bad, rng.integers(0, 2, len(bad))] = rng.choice([np.nan, np.inf, -np.inf], len(bad))
+            eps = float(rng.choice([0.5, 1.5, np.inf]))
+        else:            # far apart magnitudes: sums round
+            c = rng.random((n, 2)) * 10.0 ** rng.integers(-3, 12, size=(n, 1))
+            eps = float(rng.choice([0.3, 1e3, 1e9]))
+        mp = int(rng.integers(-1, 7))
+        shown = None if t % 3 == 0 else (rng.random(n) < 0.8).astype(np.uint8)
+        cls = None if t % 5 < 2 else (rng.random(n) < 0.3).astype(np.uint8)
+        lab0 = None if cls is None else (cls * rng.integers(1, 5, n)).astype(np.int32)
+        same(c, eps, mp, shown, cls, lab0, "pairwise trial %d kind %d n=%d eps=%r mp=%d" % (t, kind, n, eps, mp))
+    c = np.round(rng.random((6_000, 2)) * 30.0) / 3.0   # thousands of pairs within rounding of the threshold
+    same(c, 1.0 / 3.0, 5, what="6 k points on thirds")
     # a mask with the live class is still refused
     with pytest.raises(N.VcpError) as e:
         vcp_ctx.dbscan(np.zeros((4, 2)), 0.5, 2, N.L1_2D, in_mask=np.ones(4, np.uint8))

@@ -18,9 +18,9 @@
 //     loop if it is not yet reached when its turn comes, and once more when a cluster first reaches it.
 // The C# evaluates fl(fl(dx) + fl(dy)).  That equals the 1-D relation on s exactly when every coordinate is a
 // multiple of one power of two with fewer than 52 bits of span (checked on the device); otherwise it is accepted when
-// no pair of shown points sits within the rounding band of the threshold (checked too).  A cloud that fails both gets
-// VCP_ERR_UNSUPPORTED rather than a guess.  Requires e >= 0 and finite coordinates (an e < 0 makes a point not its own
-// neighbour: the class then leaves seeds unclassed -- not reproduced).
+// no pair of shown points sits within the rounding band of the threshold (checked too).  A cloud that fails both, an e < 0
+// or NaN (a point is then not its own neighbour: the class leaves seeds unclassed) and non-finite coordinates take the
+// pair-by-pair form of dbpairs.hip: the C#'s expression on every pair, O(n^2), up to 2^21 points.
 #include <string.h>
 
 #include <rocprim/rocprim.hpp>
@@ -178,8 +178,11 @@ __global__ __launch_bounds__(DT) void k_db_out(int64_t n, const uint8_t* __restr
 int vcp_db_engine(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, double eps, int min_pts, int32_t cf_in,
                   const uint8_t* d_mask, const uint8_t* d_in_classed, int32_t* d_labels, uint8_t* d_is_core,
                   uint8_t* d_is_classed, int32_t* cf_out, int64_t* dist_evals) {
-  if (!(eps >= 0.0))
-    return vcp_fail(ctx, VCP_ERR_UNSUPPORTED, "DB (BaseClass/DB.cs) with e < 0 or NaN: a point is then not its own neighbour");
+  // what the 1-D formulation below cannot take goes to the pair-by-pair form (dbpairs.hip): exact for every input, O(n^2)
+#define VCP_DB_PAIRS()                                                                                                 \
+  vcp_db_pairs_engine(ctx, d_coords, n, stride, eps, min_pts, cf_in, d_mask, d_in_classed, d_labels, d_is_core, d_is_classed, \
+                      cf_out, dist_evals)
+  if (!(eps >= 0.0)) return VCP_DB_PAIRS();  // e < 0 or NaN: a point is not its own neighbour
   if (n >= 0x7FFFFFF0LL) return vcp_fail(ctx, VCP_ERR_TOO_LARGE, "n beyond 32-bit indexing");
   hipStream_t st = ctx->stream;
   const size_t N1 = (size_t)n + 2;
@@ -210,8 +213,7 @@ int vcp_db_engine(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, d
   VCP_HIP(ctx, hipMemcpyAsync(hc, ctr, 8 * 8, hipMemcpyDeviceToHost, st));
   VCP_HIP(ctx, hipStreamSynchronize(st));
   const uint32_t m = (uint32_t)hc[0];
-  if (hc[1] != 0)
-    return vcp_fail(ctx, VCP_ERR_UNSUPPORTED, "DB (BaseClass/DB.cs): %llu non-finite coordinates among the shown points", hc[1]);
+  if (hc[1] != 0) return VCP_DB_PAIRS();  // non-finite coordinates among the shown points
   // is the C#'s fl(fl(dx) + fl(dy)) exactly s_p - s_j?  yes when all coordinates share a binary grid of < 52 bits span
   const bool have = hc[5] != 0;
   const int low = 4096 - (int)hc[5], top = (int)hc[6] - 4096;
@@ -222,6 +224,13 @@ int vcp_db_engine(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, d
   if (m > 0) hipLaunchKernelGGL(k_db_unkey, dim3(vcp_blocks(m, DT)), dim3(DT), 0, st, key_out, idx_out, m, sk, pos);
   hipLaunchKernelGGL(k_db_reach, dim3(vcp_blocks((int64_t)m + 1, DT)), dim3(DT), 0, st, sk, idx_out, m, eps, min_pts, band,
                      d_in_classed, R, lp1, ctr);
+  if (!exact) {
+    // a neighbour candidate within rounding of the threshold while the coordinates share no binary grid: the signed-sum
+    // relation is not provably 1-D -- decided before anything is written to the caller's arrays
+    VCP_HIP(ctx, hipMemcpyAsync(hc, ctr, 8 * 8, hipMemcpyDeviceToHost, st));
+    VCP_HIP(ctx, hipStreamSynchronize(st));
+    if (hc[2] != 0) return VCP_DB_PAIRS();
+  }
   VCP_TRY(vcp_exclusive_max_scan_u32(ctx, lp1, lp1, (int64_t)m + 1, nullptr));
   hipLaunchKernelGGL(k_db_fixed, dim3(vcp_blocks((int64_t)m + 2, DT)), dim3(DT), 0, st, lp1, R, m, xs);
   VCP_TRY(vcp_exclusive_max_scan_u32(ctx, xs, xs, (int64_t)m + 2, nullptr));
@@ -236,11 +245,7 @@ int vcp_db_engine(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, d
   VCP_HIP(ctx, hipMemcpyAsync(hc, ctr, 8 * 8, hipMemcpyDeviceToHost, st));
   VCP_TRY(vcp_phase_finish(ctx));
   VCP_HIP(ctx, hipStreamSynchronize(st));
-  if (!exact && hc[2] != 0)
-    return vcp_fail(ctx, VCP_ERR_UNSUPPORTED,
-                    "DB (BaseClass/DB.cs): %llu points have a neighbour candidate within rounding of the threshold and the "
-                    "coordinates do not share a binary grid -- the signed-sum relation is not provably 1-D here",
-                    hc[2]);
+#undef VCP_DB_PAIRS
   if (cf_out) *cf_out = cf_in + (int32_t)hc[3];
   if (dist_evals) *dist_evals = (int64_t)hc[4] * (int64_t)m;
   return VCP_OK;

@@ -37,3 +37,9 @@ int vcp_dbscan_engine(vcp_ctx* ctx, const double* d_coords, int64_t n, int strid
 int vcp_db_engine(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, double eps, int min_pts, int32_t cf_in,
                   const uint8_t* d_mask, const uint8_t* d_in_classed, int32_t* d_labels, uint8_t* d_is_core,
                   uint8_t* d_is_classed, int32_t* cf_out, int64_t* dist_evals);
+
+// The same class pair by pair (csrc/dbpairs.hip): exact for every input (non-finite coordinates, e < 0, clouds whose
+// signed-sum relation is not provably 1-D), O(n^2), n <= 2^21; vcp_db_engine falls back to it.
+int vcp_db_pairs_engine(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, double eps, int min_pts, int32_t cf_in,
+                        const uint8_t* d_mask, const uint8_t* d_in_classed, int32_t* d_labels, uint8_t* d_is_core,
+                        uint8_t* d_is_classed, int32_t* cf_out, int64_t* dist_evals);

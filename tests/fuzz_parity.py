@@ -162,7 +162,34 @@ def tools_case():
     done["tools"] = done.get("tools", 0) + 1
 
 
-def run(budget=300.0, seed=12345, max_log_n=6.3, gpu_bound=None, device=0, quiet=False, nn_log=4.6):
+def db_case():
+    """the dead v1.0 class DB (BaseClass/DB.cs: signed dx + dy, ifShown mask): the sort-and-scan form where its relation is
+    provably 1-D, the pair-by-pair form otherwise (no binary grid, e < 0 / NaN, non-finite coordinates) -- labels, isClassed,
+    isKeyPoint, clusterAmount, iritatorNum against the literal transcription"""
+    n = int(10 ** rng.uniform(0, 3.3))
+    c = cloud(n, 2)
+    kind = int(rng.integers(0, 4))
+    if kind == 0:
+        c = np.round(c * 4.0) / 4.0
+    elif kind == 1:
+        c = np.round(c * 3.0) / 3.0
+    span = float(np.nanmax(np.abs(np.where(np.isfinite(c), c, 0.0)))) if n else 1.0
+    eps = float(rng.choice([0.0, 0.25, 1.0 / 3.0, 1.0, -0.5, np.nan, np.inf, 0.01 * span, 0.2 * span]))
+    mp = int(rng.integers(-1, 9))
+    shown = None if rng.random() < 0.4 else (rng.random(n) < 0.8).astype(np.uint8)
+    cls = None if rng.random() < 0.5 else (rng.random(n) < 0.3).astype(np.uint8)
+    lab0 = None if cls is None else (cls * rng.integers(1, 5, n)).astype(np.int32)
+    o = O.db_literal(c, eps, mp, shown, cls, lab0)
+    g = ctx.dbscan(c, eps, mp, N.SIGNED_SUM_2D, 0, cls, lab0, in_mask=shown)
+    if not (np.array_equal(g["labels"], o["labels"]) and np.array_equal(g["is_classed"], o["classed"])
+            and np.array_equal(g["is_core"], o["is_key"]) and g["cf"] == o["cluster_amount"] and g["evals"] == o["evals"]):
+        np.savez("gpurun_out/fuzz_fail_db.npz", c=c, eps=eps, mp=mp, shown=np.zeros(0) if shown is None else shown,
+                 cls=np.zeros(0) if cls is None else cls, lab0=np.zeros(0) if lab0 is None else lab0)
+        fail("MISMATCH DB n=%d eps=%r mp=%d kind=%d" % (n, eps, mp, kind))
+    done["db"] = done.get("db", 0) + 1
+
+
+def run(budget=300.0, seed=12345, max_log_n=6.3, gpu_bound=None, device=0, quiet=False, nn_log=4.6, with_db=True):
     """One sweep of `budget` seconds from `seed`.  max_log_n: log10 of the largest DBSCAN cloud; gpu_bound: optional
     function n -> seconds, the GPU time a DBSCAN call on n points may take (the sweep found two cliffs that way: eps = 0
     with far outliers, a cloud inside one eps-ball).  Raises Mismatch on the first disagreement."""
@@ -184,6 +211,9 @@ def run(budget=300.0, seed=12345, max_log_n=6.3, gpu_bound=None, device=0, quiet
             continue
         if u < 0.3:
             tools_case()
+            continue
+        if with_db and u < 0.36:
+            db_case()
             continue
         n = int(10 ** rng.uniform(0, max_log_n))
         metric = int(rng.integers(0, 3))
@@ -260,9 +290,9 @@ def run(budget=300.0, seed=12345, max_log_n=6.3, gpu_bound=None, device=0, quiet
             done["blocks"] += 1
         if (done["dbscan"] % 50) == 0:
             say("%.0f s: %d dbscan, %d block pipelines agree" % (time.time() - t0, done["dbscan"], done["blocks"]), flush=True)
-    msg = ("OK: %d dbscan calls, %d block pipelines, %d nearest-neighbour / matching cases bit-exact and %d centroid / merge / "
-           "keyed-pipeline cases against the oracle (seed %d)" % (done["dbscan"], done["blocks"], done.get("nn", 0),
-                                                               done.get("tools", 0), seed))
+    msg = ("OK: %d dbscan calls, %d block pipelines, %d nearest-neighbour / matching cases, %d calls of the dead class DB "
+           "bit-exact and %d centroid / merge / keyed-pipeline cases against the oracle (seed %d)"
+           % (done["dbscan"], done["blocks"], done.get("nn", 0), done.get("db", 0), done.get("tools", 0), seed))
     print(msg, flush=True)
     if own:
         ctx.close()

@@ -22,3 +22,4 @@ def test_bounded_fixed_seed_sweep(vcp_ctx, oracle):
     finally:
         F.ctx = None
     assert done["dbscan"] >= 20 and done["blocks"] >= 3 and done.get("nn", 0) >= 3 and done.get("tools", 0) >= 1, done
+    assert done.get("db", 0) >= 1, done

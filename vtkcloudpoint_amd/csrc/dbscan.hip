@@ -1721,7 +1721,12 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
     range = std::fmax(range, hi - lo);
   }
   double cellw = eps * (1.0 + 1.0 / 1048576.0);
-  int64_t budget = n * 32;
+  static const int64_t cells_per_point = [] {  // (VCP_CELL_BUDGET: test switch)
+    const char* e = getenv("VCP_CELL_BUDGET");
+    const long v = e ? atol(e) : 32;
+    return (int64_t)(v < 1 ? 1 : v > 4096 ? 4096 : v);
+  }();
+  int64_t budget = n * cells_per_point;
   if (budget < (1 << 16)) budget = 1 << 16;
   if (budget > ((int64_t)1 << 31) - 16) budget = ((int64_t)1 << 31) - 16;  // cell ids and ncells + 1 stay in 31 bits
   // Robust range.  Cell indices are clamped to the grid, so ANY origin and extent give correct results (a point

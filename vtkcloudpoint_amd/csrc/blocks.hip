@@ -139,57 +139,35 @@ __global__ __launch_bounds__(BT) void k_cluster_sizes(const int32_t* __restrict_
 // Final order inside a block = stable by local id (noise, id 0, first): a counting sort per block.  Ids are counted in
 // LDS, scanned, then the block's positions are placed in order -- per chunk of 64 positions the lanes that hold the same
 // id take consecutive slots (one ballot per distinct id in the chunk).  Replaces two library radix sorts over all m
-// positions (by local id, then by block) when no block has more than CS_CAP ids.
-//   NW = 1: one wave per block, four blocks per workgroup: blocks of up to BIG_BLOCK positions (a block holds
-//           ~ptsInCell points);
-//   NW = 16: one workgroup per block of the host's list of large blocks (the heart of a blob can put 10^4 points in
-//           one rectangle; a single wave walking it set the kernel time: 415 us): every wave reads the whole block but
-//           places only the ids congruent to its number, so each cursor has one owner and the order stays stable.
-template <int NW>
-__global__ __launch_bounds__(NW == 1 ? BT : 64 * NW) void k_block_order(const int32_t* __restrict__ local,
-                                                                       const uint32_t* __restrict__ blockstart,
-                                                                       int64_t nblocks, const uint32_t* __restrict__ kb,
-                                                                       const uint32_t* __restrict__ biglist,
-                                                                       const uint32_t* __restrict__ cstart,
-                                                                       uint32_t* __restrict__ csize,
-                                                                       uint32_t* __restrict__ order, uint32_t* __restrict__ ovf,
-                                                                       uint32_t b_lo) {
-  constexpr int NG = NW == 1 ? BT / 64 : 1;  // blocks per workgroup
+// positions (by local id, then by block) when no block has more than CS_CAP ids.  One wave per block, four blocks per
+// workgroup: blocks of up to BIG_BLOCK positions (a block holds ~ptsInCell points); the larger ones: k_block_order_big.
+__global__ __launch_bounds__(BT) void k_block_order(const int32_t* __restrict__ local, const uint32_t* __restrict__ blockstart,
+                                                   int64_t nblocks, const uint32_t* __restrict__ kb,
+                                                   const uint32_t* __restrict__ cstart, uint32_t* __restrict__ csize,
+                                                   uint32_t* __restrict__ order, uint32_t* __restrict__ ovf) {
+  constexpr int NG = BT / 64;  // blocks per workgroup
   __shared__ uint32_t cnt[NG][CS_CAP + 1];
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int g = NW == 1 ? w : 0;       // which of the workgroup's blocks
-  const int me = NW == 1 ? 0 : w;      // which ids this wave places (id % NW)
-  int64_t b;
-  if (NW == 1) {
-    b = (int64_t)blockIdx.x * NG + w;
-    if (b >= nblocks) return;  // whole waves leave together; no workgroup barrier below for NW == 1
-  } else {
-    b = biglist[blockIdx.x] - b_lo;
-  }
+  const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * NG + g;
+  if (b >= nblocks) return;  // whole waves leave together; no workgroup barrier below
   const uint32_t s0 = blockstart[b], s1 = blockstart[b + 1];
-  if (NW == 1 && (s0 == s1 || s1 - s0 > BIG_BLOCK)) return;
+  if (s0 == s1 || s1 - s0 > BIG_BLOCK) return;
   const uint32_t K = kb[b];  // ids 0..K
-  const uint32_t nthr = 64 * NW, tid = NW == 1 ? lane : threadIdx.x;
-  if (K > (uint32_t)CS_CAP) {  // more ids than the LDS table: the host repeats the stage in the library-sort form
-    if (tid == 0) *ovf = 1u;
-    for (uint32_t t = s0 + tid; t < s1; t += nthr) order[t] = t;  // (what the rest of this pass reads stays in range)
-    return;  // (uniform per wave, and per workgroup for NW > 1)
+  if (K > (uint32_t)CS_CAP || K == 0u) {  // (uniform per wave)
+    if (K != 0u && lane == 0) *ovf = 1u;  // more ids than the LDS table: the host repeats the stage in the library-sort form
+    for (uint32_t t = s0 + lane; t < s1; t += 64) order[t] = t;  // nothing but noise (most blocks of a scan's background): the list's order
+    return;
   }
-  if (K == 0u) {  // nothing but noise (most blocks of a scan's background): the order is the list's
-    for (uint32_t t = s0 + tid; t < s1; t += nthr) order[t] = t;
-    return;  // (uniform per wave, and per workgroup for NW > 1)
-  }
-  for (uint32_t k = tid; k <= K; k += nthr) cnt[g][k] = 0;
-  if (NW == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();
-  for (uint32_t t = s0 + tid; t < s1; t += nthr) atomicAdd(&cnt[g][local[t]], 1u);
-  if (NW == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+  for (uint32_t k = lane; k <= K; k += 64) cnt[g][k] = 0;
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t t = s0 + lane; t < s1; t += 64) atomicAdd(&cnt[g][local[t]], 1u);
+  __builtin_amdgcn_wave_barrier();
   {  // the counts of ids 1..K are the cluster sizes CompleteWork3's demotion rule needs (k_keep)
     const uint32_t c0 = cstart[b];
-    for (uint32_t k = 1 + tid; k <= K; k += nthr) csize[c0 + k - 1] = cnt[g][k];
+    for (uint32_t k = 1 + lane; k <= K; k += 64) csize[c0 + k - 1] = cnt[g][k];
   }
-  if (NW == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();
-  if (w == 0 || NW == 1) {
-    // exclusive scan of cnt[0..K] by one wave, 64 entries per trip
+  __builtin_amdgcn_wave_barrier();
+  {  // exclusive scan of cnt[0..K], 64 entries per trip
     uint32_t carry = s0;
     for (uint32_t k0 = 0; k0 <= K; k0 += 64) {
       const uint32_t k = k0 + lane;
@@ -204,41 +182,30 @@ __global__ __launch_bounds__(NW == 1 ? BT : 64 * NW) void k_block_order(const in
       carry += __shfl(inc, 63, 64);
     }
   }
-  if (NW == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();
-  // NW > 1: the ids come through LDS in tiles loaded by the whole workgroup (a wave walking a large block chunk by chunk
-  // would wait for one global load per chunk: 400 dependent loads for 25 k points)
-  constexpr uint32_t TILE = NW == 1 ? 64 : 8192;
-  __shared__ uint16_t ids[NW == 1 ? 1 : TILE];
-  for (uint32_t tile0 = s0; tile0 < s1; tile0 += TILE) {
-    const uint32_t tend = min(tile0 + TILE, s1);
-    if (NW > 1) {
-      __syncthreads();  // the previous tile has been consumed
-      for (uint32_t t = tile0 + tid; t < tend; t += nthr) ids[t - tile0] = (uint16_t)local[t];  // ids <= CS_CAP
-      __syncthreads();
-    }
-    for (uint32_t t0 = tile0; t0 < tend; t0 += 64) {
-      const uint32_t t = t0 + lane;
-      const uint32_t id = t < tend ? (NW == 1 ? (uint32_t)local[t] : (uint32_t)ids[t - tile0]) : 0xFFFFFFFFu;
-      const bool mine = t < tend && (NW == 1 || id % NW == (uint32_t)me);
-      unsigned long long todo = __ballot(mine);
-      while (todo) {
-        const int first = __ffsll((long long)todo) - 1;
-        const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)id, first);  // (first is uniform: a scalar lane select)
-        const unsigned long long same = __ballot(mine && id == cur);
-        const uint32_t base = cnt[g][cur];
-        if (mine && id == cur) order[base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = t;
-        __builtin_amdgcn_wave_barrier();
-        if (lane == first) cnt[g][cur] = base + (uint32_t)__popcll(same);
-        __builtin_amdgcn_wave_barrier();
-        todo &= ~same;
-      }
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t t0 = s0; t0 < s1; t0 += 64) {
+    const uint32_t t = t0 + lane;
+    const bool mine = t < s1;
+    const uint32_t id = mine ? (uint32_t)local[t] : 0xFFFFFFFFu;
+    unsigned long long todo = __ballot(mine);
+    while (todo) {
+      const int first = __ffsll((long long)todo) - 1;
+      const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)id, first);  // (first is uniform: a scalar lane select)
+      const unsigned long long same = __ballot(mine && id == cur);
+      const uint32_t base = cnt[g][cur];
+      if (mine && id == cur) order[base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = t;
+      __builtin_amdgcn_wave_barrier();
+      if (lane == first) cnt[g][cur] = base + (uint32_t)__popcll(same);
+      __builtin_amdgcn_wave_barrier();
+      todo &= ~same;
     }
   }
 }
 // Large blocks (the host's list), second form: one workgroup of 16 waves per block, wave w owns the w-th contiguous segment
 // of the block.  Counts per (id, wave) in LDS, ONE flat exclusive scan in (id, wave) order -- which is the stable order --
-// and every wave places its own segment with its own cursors: each position is read twice by one wave (k_block_order<16>
-// has every wave read the whole block: 146 us for the thousand large blocks of the 10 M-point cloud).
+// and every wave places its own segment with its own cursors: each position is read twice by one wave (the form before it
+// had every wave read the whole block and place the ids congruent to its number: 146 us for the thousand large blocks of
+// the 10 M-point cloud, 70 us now).
 constexpr int OBW = 16;
 constexpr int OBS = OBW + 1;  // row stride of the counters: the lanes of a wave (same w, different ids) hit different banks
 __global__ __launch_bounds__(64 * OBW) void k_block_order_big(const int32_t* __restrict__ local,
@@ -996,8 +963,8 @@ int finish_local(vcp_ctx* ctx, const int32_t* d_local, bool sharded, bool force_
   bool by_sort = force_sort || getenv("VCP_BLOCKS_ORDER_SORT") != nullptr;  // (the variable: test switch)
   for (;;) {
     if (m > 0 && !by_sort) {
-      hipLaunchKernelGGL(k_block_order<1>, dim3(nbw), dim3(BT), 0, st, d_local, blockstart, nb, kb, nullptr, cstart, csize,
-                         order, dmisc + 4, b_lo);
+      hipLaunchKernelGGL(k_block_order, dim3(nbw), dim3(BT), 0, st, d_local, blockstart, nb, kb, cstart, csize, order,
+                         dmisc + 4);
       if (s->nbig)
         hipLaunchKernelGGL(k_block_order_big, dim3(s->nbig), dim3(64 * OBW), 0, st, d_local, blockstart, kb,
                            s->biglist.as<uint32_t>(), cstart, csize, order, dmisc + 4, b_lo);

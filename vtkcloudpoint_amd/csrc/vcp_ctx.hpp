@@ -30,7 +30,13 @@ struct vcp_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   hipDeviceProp_t prop;
-  // pinned scratch for tiny readbacks
+  // pinned scratch for tiny readbacks (64 KB).  Who reads back where (byte offsets; a context runs one call at a time on
+  // one stream, and every user has consumed its words before the call that wrote them returns or goes on):
+  //   [0, 1024)     the DBSCAN engine: bounds, counters, work sizes (dbscan.hip); the block partition's bounds (blockpart.hip);
+  //                 the finish stage's counters (blocks.hip)
+  //   [1024, 2048)  the partition's SelState (blockpart.hip); the all-pairs kernel's counters (blocks.hip: blocks_cluster);
+  //                 DB's counters (dbdead.hip, dbpairs.hip)
+  //   [2048, 2064)  DB pair by pair: next seed / frontier size (dbpairs.hip)
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
   // pinned staging area of the host-buffer entry points with several small arrays (vcp_stage; grown on demand, <= 64 MiB)

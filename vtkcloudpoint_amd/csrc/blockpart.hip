@@ -207,11 +207,13 @@ __global__ __launch_bounds__(PT) void k_sel_init(SelState* __restrict__ st, uint
   }
 }
 
-__global__ __launch_bounds__(PT) void k_sel_hist(const double* __restrict__ key, int64_t n, double x_Min, double y_Min,
+// mm: the bounds pass's result in device memory ([0] x min, [2] y min): the selection starts without a host round trip
+__global__ __launch_bounds__(PT) void k_sel_hist(const double* __restrict__ key, int64_t n, const double* __restrict__ mm,
                                                  uint32_t chunk, uint32_t pass, const SelState* __restrict__ st,
                                                  uint32_t* __restrict__ ghist) {
   __shared__ uint32_t h[4096];
   if (st->done) return;
+  const double x_Min = mm[0], y_Min = mm[2];
   for (uint32_t k = threadIdx.x; k < 4096u; k += PT) h[k] = 0u;
   __syncthreads();
   const unsigned long long phi = st->phi, plo = st->plo;
@@ -282,10 +284,11 @@ __global__ __launch_bounds__(PT) void k_sel_pick(SelState* __restrict__ st, uint
 }
 
 // keys below the prefix are in the first block for sure (their x, y feed its extent); keys that match it are candidates
-__global__ __launch_bounds__(PT) void k_sel_collect(const double* __restrict__ key, int64_t n, double x_Min, double y_Min,
+__global__ __launch_bounds__(PT) void k_sel_collect(const double* __restrict__ key, int64_t n, const double* __restrict__ mm,
                                                     uint32_t chunk, SelState* __restrict__ st, Cand* __restrict__ cand,
                                                     double* __restrict__ part) {
   if (st->done || !st->collect) return;
+  const double x_Min = mm[0], y_Min = mm[2];
   const unsigned long long phi = st->phi, plo = st->plo;
   const uint32_t nbits = 12u * st->pass;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1013,26 +1016,16 @@ int vcp_blocks_plan(vcp_ctx* ctx, BlocksState* s, const double* d_key, const dou
   double* part = s->misc.as<double>();
   double* out = part + (size_t)rb * 5;
   double* h = reinterpret_cast<double*>(ctx->pinned);
+  // The bounds stay on the device for the selection's first pass (k_sel_hist / k_sel_collect read them there) and come to
+  // the host together with its result: one read-back for bounds + selection instead of two (three with a separate key).
+  double* out_motor = out + 8;
   if (keyed) {
     // a non-finite motor coordinate would reach DBImproved only; the partition's own check below covers the keys
     hipLaunchKernelGGL(k_minmax2_part, dim3(rb), dim3(BT), 0, st, d_motor, n, part);
-    hipLaunchKernelGGL(k_minmax2_final, dim3(1), dim3(BT), 0, st, part, rb, out);
-    VCP_HIP(ctx, hipMemcpyAsync(h, out, 5 * 8, hipMemcpyDeviceToHost, st));
-    VCP_HIP(ctx, hipStreamSynchronize(st));
-    if (h[4] != 0.0) return vcp_fail(ctx, VCP_ERR_ARG, "non-finite motor coordinates");
-    for (int k = 0; k < 4; k++) s->mbox[k] = h[k];
+    hipLaunchKernelGGL(k_minmax2_final, dim3(1), dim3(BT), 0, st, part, rb, out_motor);
   }
   hipLaunchKernelGGL(k_minmax2_part, dim3(rb), dim3(BT), 0, st, d_key, n, part);
   hipLaunchKernelGGL(k_minmax2_final, dim3(1), dim3(BT), 0, st, part, rb, out);
-  VCP_HIP(ctx, hipMemcpyAsync(h, out, 5 * 8, hipMemcpyDeviceToHost, st));
-  VCP_HIP(ctx, hipStreamSynchronize(st));
-  if (h[4] != 0.0) return vcp_fail(ctx, VCP_ERR_ARG, "non-finite partition coordinates");
-  s->x_Min = h[0];
-  s->x_Max = h[1];
-  s->y_Min = h[2];
-  s->y_Max = h[3];
-  if (!keyed)
-    for (int k = 0; k < 4; k++) s->mbox[k] = h[k];
 
   // chunks of the passes over the list
   int64_t chunk = (n + 255) / 256;
@@ -1055,14 +1048,23 @@ int vcp_blocks_plan(vcp_ctx* ctx, BlocksState* s, const double* d_key, const dou
   SelState* hs = reinterpret_cast<SelState*>(reinterpret_cast<char*>(ctx->pinned) + 1024);
   bool done = false;
   for (uint32_t pass = 0; pass < 8 && !done; pass++) {
-    hipLaunchKernelGGL(k_sel_hist, dim3(nchunk), dim3(PT), 0, st, d_key, n, s->x_Min, s->y_Min, (uint32_t)chunk, pass, d_sel,
-                       ghist);
+    hipLaunchKernelGGL(k_sel_hist, dim3(nchunk), dim3(PT), 0, st, d_key, n, out, (uint32_t)chunk, pass, d_sel, ghist);
     hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(PT), 0, st, d_sel, ghist);
-    hipLaunchKernelGGL(k_sel_collect, dim3(nchunk), dim3(PT), 0, st, d_key, n, s->x_Min, s->y_Min, (uint32_t)chunk, d_sel,
+    hipLaunchKernelGGL(k_sel_collect, dim3(nchunk), dim3(PT), 0, st, d_key, n, out, (uint32_t)chunk, d_sel,
                        s->cand.as<Cand>(), selpart);
     hipLaunchKernelGGL(k_sel_final, dim3(1), dim3(PT), 0, st, d_sel, s->cand.as<Cand>(), selpart, nchunk);
     VCP_HIP(ctx, hipMemcpyAsync(hs, d_sel, sizeof(SelState), hipMemcpyDeviceToHost, st));
+    if (pass == 0) VCP_HIP(ctx, hipMemcpyAsync(h, out, 16 * 8, hipMemcpyDeviceToHost, st));  // both sets of bounds
     VCP_HIP(ctx, hipStreamSynchronize(st));
+    if (pass == 0) {
+      if (keyed && h[8 + 4] != 0.0) return vcp_fail(ctx, VCP_ERR_ARG, "non-finite motor coordinates");
+      if (h[4] != 0.0) return vcp_fail(ctx, VCP_ERR_ARG, "non-finite partition coordinates");
+      s->x_Min = h[0];
+      s->x_Max = h[1];
+      s->y_Min = h[2];
+      s->y_Max = h[3];
+      for (int k = 0; k < 4; k++) s->mbox[k] = keyed ? h[8 + k] : h[k];
+    }
     done = hs->done != 0;
   }
   if (!done) return vcp_fail(ctx, VCP_ERR_HIP, "the selection of the first block did not finish");

@@ -1,17 +1,19 @@
 // blocks.hip -- the reference's block-partitioned clustering ("v2.0 multithread") on MI355X.
 //
-//   begin   = MainForm.getClusterFromMotor, FrmMain.cs:1214-1291: bounds, stable sort by
+//   begin   = MainForm.getClusterFromMotor, FrmMain.cs:1214-1291: bounds, order by
 //             max(x-xmin, y-ymin), first ptsInCell points -> block size, (lo,hi] rectangle blocks
-//             (Tools.getListByScale2, BaseClass/Tools.cs:510-513), block-major list
-//   cluster = StartCode, FrmMain.cs:2782-2794: one DBImproved(cf=0) per block -- here ONE grouped launch of
-//             the DBSCAN engine over a contiguous range of blocks (the unit of multi-GPU sharding)
+//             (Tools.getListByScale2, BaseClass/Tools.cs:510-513), block-major list (blockpart.hip)
+//   cluster = StartCode, FrmMain.cs:2782-2794: one DBImproved(cf=0) per block -- here, over a contiguous range of
+//             blocks (the unit of multi-GPU sharding): the blocks of up to 1024 points by an all-pairs kernel in LDS
+//             (k_block_brute), the larger ones in ONE grouped launch of the DBSCAN engine
 //   finish  = CompleteWork3, FrmMain.cs:1442-1520: per block stable order by local id, global renumber,
 //             demotion of clusters of <= small_max points (with the reference's clusLen quirks), one
 //             global DBImproved over all noise with cf preset, final clusForMerge order
 //
 // Declared deviations from the C# (same as the oracle): List.Sort's unstable tie order is
 // replaced by a stable order; a block-0 point is never also filed under a rectangle; clusterSum is
-// summed deterministically.  Sorting uses rocPRIM's stable LSD radix sort.
+// summed deterministically.  The partition (blockpart.hip) sorts nothing; rocPRIM's stable radix sort remains for the
+// rare form of CompleteWork3's order when a block has more cluster ids than the LDS table of the counting sort.
 #include <string.h>  // rocprim's texture_cache_iterator.hpp calls ::memset without including it
 
 #include <rocprim/rocprim.hpp>

@@ -1143,7 +1143,7 @@ void vcp_blocks_state_free(vcp_ctx* ctx) {
                    &s->gtwice, &s->gnclus, &s->tmp0, &s->tmp1, &s->tmp2, &s->tmp3, &s->sorttmp, &s->blk_t, &s->csize,
                    &s->cstart, &s->kb, &s->zb, &s->keep, &s->order, &s->newlab, &s->zflag, &s->zlist, &s->zcoords,
                    &s->zlab, &s->misc, &s->biglist, &s->sel, &s->cand, &s->counts, &s->rec, &s->rec2, &s->stage, &s->rank, &s->binfo, &s->slicelist,
-                   &s->vlist, &s->fall, &s->gcnt, &s->grp_big, &s->brutecnt};
+                   &s->vlist, &s->fall, &s->gcnt, &s->grp_big, &s->brutecnt, &s->counts_t};
   for (DevBuf* b : all)
     if (b->p) (void)hipFree(b->p);
   if (s->side) {

@@ -17,7 +17,7 @@ struct BlocksState {
   DevBuf motor, pkey, blockof, bl, motor_bm, blockstart, gtwice, gnclus, tmp0, tmp1, tmp2, tmp3, sorttmp, blk_t, csize,
       cstart, kb, zb, keep, order, newlab, zflag, zlist, zcoords, zlab, misc;
   // partition workspace (blockpart.hip)
-  DevBuf sel, cand, counts, rec, rec2, stage, rank, binfo, slicelist, vlist, fall, gcnt;
+  DevBuf sel, cand, counts, counts_t, rec, rec2, stage, rank, binfo, slicelist, vlist, fall, gcnt;
   // blocks of at most brute_thr points are clustered by the all-pairs kernel (blocks.hip: k_block_brute), the others by the
   // grid engine, which reads grp_big [m]: the block id of a point of a larger block, -1 for the others (0 = engine only)
   uint32_t brute_thr = 0;

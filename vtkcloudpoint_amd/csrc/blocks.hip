@@ -1110,6 +1110,9 @@ int blocks_finish(vcp_ctx* ctx, const int32_t* d_local, int64_t evals_blocks, in
     DbscanExt zext;  // the noise points lie inside the cloud's box
     const double bbox[6] = {s->mbox[0], s->mbox[2], 0.0, s->mbox[1], s->mbox[3], 0.0};
     zext.h_bbox = bbox;
+    // the noise points are spread over the cloud's box unless far outliers stretch it -- which shows in the block grid: a
+    // first block of ptsInCell points that is a speck of the box means rows x cols far beyond n / ptsInCell
+    zext.no_trim = (double)s->nblocks <= 16.0 * ((double)s->n / (double)std::max(s->take, 1) + 1.0);
     VCP_TRY(vcp_dbscan_engine(ctx, s->zcoords.as<double>(), (int64_t)A, 2, VCP_L1_2D, s->eps, s->min_pts, (int32_t)kept,
                               nullptr, s->zlab.as<int32_t>(), nullptr, nullptr, &cf, &ev, &zext));
   }

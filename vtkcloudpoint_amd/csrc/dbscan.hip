@@ -1747,7 +1747,8 @@ int run_dbscan(vcp_ctx* ctx, const double* d_coords, int64_t n, int stride, doub
       return c;
     };
     double lo[3] = {h[0], h[1], h[2]}, hi[3] = {h[3], h[4], h[5]};
-    for (int it = 0; it < 8 && cellw >= 0.0 && std::isfinite(cellw) && !(cells_needed(lo, hi) <= (double)budget); it++) {
+    const bool no_trim = ext && ext->no_trim;
+    for (int it = 0; it < 8 && !no_trim && cellw >= 0.0 && std::isfinite(cellw) && !(cells_needed(lo, hi) <= (double)budget); it++) {
       Range3 R;
       for (int a = 0; a < 3; a++) {
         R.lo[a] = lo[a];

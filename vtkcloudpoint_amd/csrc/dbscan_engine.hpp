@@ -25,6 +25,9 @@ struct DbscanExt {
   // grouped calls: groups of at most this many points are somebody else's (their points carry group -1): no statistics
   // are written for them
   uint32_t skip_upto = 0;
+  // the caller knows that the box holds no far outliers (points spread over it): when the eps-grid over the box exceeds the
+  // cell budget, coarsen at once instead of first trying to trim the range to mean +- 8 sigma (a pass + a host round trip)
+  bool no_trim = false;
 };
 
 // d_* are device pointers; cf_out / dist_evals host pointers (may be null).  stride = doubles per point.

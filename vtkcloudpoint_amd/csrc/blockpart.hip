@@ -12,11 +12,13 @@
 //             the largest x and y of everything below them (k_sel_collect) and one workgroup finishes the selection and
 //             the first block's extent (k_sel_final).  On ordinary clouds the first digit -- sign and exponent of d --
 //             already isolates a few hundred keys: two passes over the coordinates in all.
-//   partition two-level split by block id: per chunk of the input an LDS histogram over super-buckets of 2^fsh consecutive
-//             block ids (k_blk_hist, which also stores the block of every point), one scan, a scatter of 32-byte records
-//             (motor coordinates, bits of d, index, block) through LDS cursors (k_blk_scatter), and one workgroup per
-//             super-bucket that counts per block, publishes the block starts and moves the records into block order
-//             (k_blk_split).  Points that fall in no block ride along as block `nblocks` (they end up behind the m
+//   partition per chunk of the input an LDS histogram over buckets (k_blk_hist, which also stores the block of every
+//             point; the counts chunk-major, transposed for the one scan that wants them bucket-major and back), then a
+//             scatter of 32-byte records (motor coordinates, bits of d, index, block) through LDS cursors (k_blk_scatter).
+//             Up to 32768 blocks every block is its own bucket: the records land in block order and the block starts are
+//             the scanned counts (k_blk_starts).  Beyond, a bucket is a super-bucket of 2^fsh consecutive block ids and one
+//             workgroup per super-bucket counts per block, publishes the block starts and moves the records into block
+//             order (k_blk_split).  Points that fall in no block ride along as block `nblocks` (they end up behind the m
 //             points that did).
 //   order     inside a block: ranks by distribution.  d spans a known range inside a block, so a monotone map of d onto
 //             ~m/2 sub-buckets (k_blk_sort) leaves groups of a few records; a record's final place is its group's start
